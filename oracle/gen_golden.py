@@ -1,0 +1,306 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (build container only).
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz
+
+The reference Python under /root/reference is imported here and ONLY here; it never travels to
+the GPU box.  Its un-vendored third-party imports (timm, flash_attn, iopath, simplejson) are
+absent from this image, so throw-away import shims are installed into ``sys.modules`` first:
+
+  * ``timm.models.vision_transformer.Mlp``   -- restated from timm (pinned ``timm==0.3.2`` by
+    OCTCube/main_pretrain.py:27; unpinned in requirement.txt): fc1 -> act_layer() -> drop -> fc2 -> drop
+  * ``timm.models.vision_transformer.DropPath`` -- stochastic depth (identity at p=0 / eval)
+  * ``timm.models.layers.to_2tuple``
+  * ``flash_attn.models.vit.create_block``    -- raises: the flash path (flash-attn==2.5.2, CUDA
+    only) cannot run here; BASELINE pins parity to the non-flash semantics
+  * ``iopath.common.file_io.g_pathmgr``, ``simplejson`` -- logging plumbing only
+
+Everything numerical other than ``Mlp`` is executed from the reference's own source files:
+Pre-training/models_mae_joint_res_flash_attn.py and Pre-training/custom_util/video_vit.py.
+
+Golden files (all small):
+  mae3d_small.npz    reduced-width model (enc 128/2 heads of 64, dec 64/2 heads of 32), weights,
+                     inputs, injected noise, reference loss / pred / mask / ids_restore / grads
+  mae3d_small_hr.npz same weights, high-res (2-D/512-style) branch: T=3 frames through
+                     high_res_patch_embed, un-interpolated spatial table
+  masking.npz        random_masking on tie-free and tie-containing noise rows at L=5120
+  train_utils.npz    get_grad_norm_, add_weight_decay grouping, adjust_learning_rate samples,
+                     one torch AdamW step (the optimizer the reference driver constructs)
+  vitl_pins.npz      full ViT-L scalar pins (loss, mask sum, pred samples, ids checksum)
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference/Pre-training"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+
+def install_shims():
+    def mod(name):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+
+    timm = mod("timm"); models = mod("timm.models"); layers = mod("timm.models.layers")
+    vt = mod("timm.models.vision_transformer"); tl = mod("timm.layers")
+    timm.models = models; models.layers = layers; models.vision_transformer = vt; timm.layers = tl
+
+    def to_2tuple(x):
+        return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+    class DropPath(nn.Module):
+        def __init__(self, drop_prob=0.0):
+            super().__init__(); self.drop_prob = drop_prob
+
+        def forward(self, x):
+            if self.drop_prob == 0.0 or not self.training:
+                return x
+            keep = 1 - self.drop_prob
+            shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+            return x.div(keep) * (keep + torch.rand(shape, dtype=x.dtype, device=x.device)).floor_()
+
+    class Mlp(nn.Module):
+        def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+            super().__init__()
+            out_features = out_features or in_features
+            hidden_features = hidden_features or in_features
+            self.fc1 = nn.Linear(in_features, hidden_features)
+            self.act = act_layer()
+            self.fc2 = nn.Linear(hidden_features, out_features)
+            self.drop = nn.Dropout(drop)
+
+        def forward(self, x):
+            return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+    layers.to_2tuple = to_2tuple; tl.to_2tuple = to_2tuple
+    vt.DropPath = DropPath; vt.Mlp = Mlp
+
+    fa = mod("flash_attn"); fam = mod("flash_attn.models"); fav = mod("flash_attn.models.vit")
+    fa.models = fam; fam.vit = fav
+
+    def create_block(*a, **k):
+        raise RuntimeError("flash-attn is CUDA-only; the oracle uses the non-flash path")
+    fav.create_block = create_block
+
+    io = mod("iopath"); ioc = mod("iopath.common"); iof = mod("iopath.common.file_io")
+    io.common = ioc; ioc.file_io = iof
+
+    class _PM:
+        def open(self, *a, **k):
+            return open(*a, **k)
+    iof.g_pathmgr = _PM()
+    sj = mod("simplejson")
+    sj.dumps = json.dumps; sj.loads = json.loads
+
+
+def build_reference(cfg, use_grad=True):
+    import models_mae_joint_res_flash_attn as ref
+    from functools import partial
+    model = ref.MaskedAutoencoderViT(
+        input_size=cfg.input_size, patch_size=cfg.patch_size, in_chans=cfg.in_chans,
+        embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
+        decoder_embed_dim=cfg.decoder_embed_dim, decoder_depth=cfg.decoder_depth,
+        decoder_num_heads=cfg.decoder_num_heads, mlp_ratio=cfg.mlp_ratio,
+        norm_layer=partial(nn.LayerNorm, eps=cfg.ln_eps), norm_pix_loss=cfg.norm_pix_loss,
+        num_frames=cfg.num_frames, t_patch_size=cfg.t_patch_size, sep_pos_embed=True,
+        cls_embed=True, pred_t_dim=cfg.pred_t_dim, high_res_input_size=cfg.high_res_input_size,
+        use_flash_attn=False)
+    return model
+
+
+def run_reference(model, imgs, noise_seed, mask_ratio, frame_loss=False):
+    """Runs the reference forward with its own torch.rand call reproducing `noise`:
+    nothing before random_masking consumes RNG (models_mae…:374-406)."""
+    torch.manual_seed(noise_seed)
+    out = model(imgs, mask_ratio=mask_ratio, frame_loss=frame_loss)
+    return out
+
+
+def tie_free(noise):
+    s, _ = torch.sort(noise, dim=1)
+    return bool((s[:, 1:] != s[:, :-1]).all())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-vitl", action="store_true")
+    args = ap.parse_args()
+    install_shims()
+    sys.path.insert(0, REF)
+    os.chdir(REF)
+    import builtins
+    from oracle import mae3d_ref as O
+
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    torch.set_num_threads(8)
+
+    # ------------------------------------------------------------------ small model
+    cfg = O.MAEConfig(input_size=64, patch_size=16, in_chans=1, embed_dim=128, depth=2, num_heads=2,
+                      decoder_embed_dim=64, decoder_depth=2, decoder_num_heads=2, num_frames=12,
+                      t_patch_size=3, pred_t_dim=12, high_res_input_size=128)
+    model = build_reference(cfg)
+    P = O.init_params(cfg, seed=7, bias_std=0.02)
+    missing = model.load_state_dict(P, strict=True)
+    assert set(model.state_dict().keys()) == set(P.keys()), "key mismatch vs oracle.param_shapes"
+    g = torch.Generator().manual_seed(11)
+    imgs = torch.rand(2, 1, 12, 64, 64, generator=g)
+    noise_seed = None
+    for s in range(1000, 2000):                      # seed-search a tie-free noise draw
+        torch.manual_seed(s)
+        nz = torch.rand(2, cfg.num_patches)
+        if tie_free(nz):
+            noise_seed = s; noise = nz; break
+    model.train()
+    (loss, fl), pred, mask = run_reference(model, imgs, noise_seed, 0.75, frame_loss=True)
+    model.zero_grad()
+    loss.backward()
+    grads = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p))
+             for k, p in model.named_parameters()}
+    # ids_restore from the reference's own random_masking on the same noise
+    torch.manual_seed(noise_seed)
+    xm, m2, ids_restore, ids_keep = model.random_masking(torch.zeros(2, cfg.num_patches, 4), 0.75)
+    assert torch.equal(m2, mask)
+    # weights are regenerated by oracle.init_params(cfg, seed=7, bias_std=0.02) (torch CPU generator, same
+    # image on both sides); a checksum pins that.  Large gradients are stored strided (every 7th) + norm.
+    save = {"param_seed": 7, "param_bias_std": 0.02,
+            "param_checksum": np.array([float(v.double().sum()) for v in P.values()]).sum(),
+            "param_abs_checksum": np.array([float(v.double().abs().sum()) for v in P.values()]).sum()}
+    for k, v in grads.items():
+        save[f"gnorm/{k}"] = float(v.double().norm())
+        save[f"grad/{k}"] = v.numpy() if v.numel() <= 8192 else v.flatten()[::7].numpy()
+    save.update(imgs=imgs.numpy(), noise=noise.numpy(), loss=loss.detach().numpy(), pred=pred.detach().numpy(),
+                mask=mask.numpy(), ids_restore=ids_restore.numpy(), ids_keep=ids_keep.numpy(),
+                frame_losses=fl.detach().numpy(), cfg=json.dumps(cfg.__dict__), mask_ratio=0.75)
+    np.savez_compressed(os.path.join(out_dir, "mae3d_small.npz"), **save)
+    print("small: loss", float(loss), "pred", tuple(pred.shape))
+
+    # norm_pix_loss variant + mask_ratio 0.9 (shipped launch config) on the same weights
+    model.norm_pix_loss = True
+    loss_np, pred_np, mask_np = run_reference(model, imgs, noise_seed, 0.9)
+    model.norm_pix_loss = False
+    # high-res branch (512-style 2-D batch: T = t_patch frames) -- pos-embeds NOT interpolated
+    imgs_hr = torch.rand(2, 1, 3, 128, 128, generator=g)
+    for s in range(3000, 4000):
+        torch.manual_seed(s)
+        nz = torch.rand(2, 64)
+        if tie_free(nz):
+            hr_seed = s; noise_hr = nz; break
+    loss_hr, pred_hr, mask_hr = run_reference(model, imgs_hr, hr_seed, 0.75)
+    np.savez_compressed(os.path.join(out_dir, "mae3d_small_variants.npz"),
+                        loss_normpix_r90=loss_np.detach().numpy(), mask_r90=mask_np.numpy(),
+                        pred_r90=pred_np.detach().numpy(),
+                        imgs_hr=imgs_hr.numpy(), noise_hr=noise_hr.numpy(), loss_hr=loss_hr.detach().numpy(),
+                        pred_hr=pred_hr.detach().numpy(), mask_hr=mask_hr.numpy())
+    print("variants: normpix/r90", float(loss_np), "hr", float(loss_hr))
+
+    # ------------------------------------------------------------------ masking at L=5120
+    L = 5120
+    rows_free, rows_tie = [], []
+    s = 0
+    while len(rows_free) < 4 or len(rows_tie) < 4:
+        torch.manual_seed(50_000 + s); s += 1
+        nz = torch.rand(1, L)
+        (rows_free if tie_free(nz) else rows_tie).append(nz)
+    nz_free = torch.cat(rows_free[:4]); nz_tie = torch.cat(rows_tie[:4])
+    model_dummy = model
+
+    def ref_mask(nz, ratio):
+        # call the reference's random_masking with torch.rand patched to return our rows
+        real = torch.rand
+        torch.rand = lambda *a, **k: nz.clone()
+        try:
+            x = torch.arange(nz.shape[0] * L, dtype=torch.float32).view(nz.shape[0], L, 1)
+            xm, mk, ir, ik = model_dummy.random_masking(x, ratio)
+        finally:
+            torch.rand = real
+        return xm, mk, ir, ik
+    xm, mk, ir, ik = ref_mask(nz_free, 0.75)
+    xm9, mk9, ir9, ik9 = ref_mask(nz_free, 0.9)
+    xmt, mkt, irt, ikt = ref_mask(nz_tie, 0.75)
+    np.savez_compressed(os.path.join(out_dir, "masking.npz"),
+                        noise_free=nz_free.numpy(), mask_free=mk.numpy(), ids_restore_free=ir.numpy(),
+                        ids_keep_free=ik.numpy(), mask_free_r90=mk9.numpy(), ids_keep_free_r90=ik9.numpy(),
+                        noise_tie=nz_tie.numpy(), mask_tie=mkt.numpy(), ids_restore_tie=irt.numpy(),
+                        ids_keep_tie=ikt.numpy())
+    print("masking: tie-free rows", nz_free.shape, "tie rows", nz_tie.shape)
+
+    # ------------------------------------------------------------------ train utilities
+    import custom_util.lr_sched as lr_sched
+    import custom_util.misc as ref_misc     # imports cleanly with the shims (psutil/matplotlib present)
+    ns = {"get_grad_norm_": ref_misc.get_grad_norm_, "add_weight_decay": ref_misc.add_weight_decay}
+    gl = [g_ for g_ in grads.values()]
+
+    class _P:   # parameter stand-in with .grad
+        def __init__(self, g_): self.grad = g_
+    gn = ns["get_grad_norm_"]([_P(g_) for g_ in gl])
+    groups = ns["add_weight_decay"](model, 0.05)
+    id2name = {id(p): n for n, p in model.named_parameters()}
+    no_decay = [id2name[id(p)] for p in groups[0]["params"]]
+    decay = [id2name[id(p)] for p in groups[1]["params"]]
+
+    class A: pass
+    a = A(); a.lr = 1.6e-3; a.min_lr = 1e-6; a.warmup_epochs = 5; a.epochs = 50
+    eps_ = [0.0, 0.37, 2.5, 5.0, 5.01, 17.3, 49.99]
+
+    class Opt:
+        def __init__(self): self.param_groups = [{"lr": 0.0}, {"lr": 0.0, "lr_scale": 0.5}]
+    lrs = []
+    for e in eps_:
+        o = Opt(); lrs.append([lr_sched.adjust_learning_rate(o, e, a), o.param_groups[0]["lr"], o.param_groups[1]["lr"]])
+    # one AdamW step exactly as the driver builds the optimizer (main_pretrain…:441-455)
+    m2 = build_reference(cfg); m2.load_state_dict(P)
+    pg = ns["add_weight_decay"](m2, 0.05)
+    opt = torch.optim.AdamW(pg, lr=1.6e-3, betas=(0.9, 0.95))
+    for n_, p_ in m2.named_parameters():
+        p_.grad = grads[n_].clone()
+    opt.step()
+    for n_, p_ in m2.named_parameters():
+        p_.grad = 0.5 * grads[n_]
+    opt.step()
+    after = {f"adamw2/{k}": v.detach().numpy() for k, v in m2.state_dict().items()
+             if k in ("blocks.0.attn.q.weight", "blocks.1.mlp.fc1.bias", "norm.weight", "mask_token",
+                      "pos_embed_temporal", "decoder_blocks.1.attn.proj.weight")}
+    np.savez_compressed(os.path.join(out_dir, "train_utils.npz"), grad_norm=gn.numpy(),
+                        no_decay=json.dumps(no_decay), decay=json.dumps(decay), lr_epochs=np.array(eps_),
+                        lr_values=np.array(lrs), **after)
+    print("train utils: grad_norm", float(gn), "groups", len(no_decay), len(decay))
+
+    # ------------------------------------------------------------------ ViT-L scalar pins
+    if not args.skip_vitl:
+        cfgL = O.VIT_L
+        modelL = build_reference(cfgL)
+        PL = O.init_params(cfgL, seed=0, bias_std=0.0)
+        modelL.load_state_dict(PL, strict=True)
+        gi = torch.Generator().manual_seed(0)
+        imgsL = torch.rand(1, 1, 60, 256, 256, generator=gi)
+        for s in range(1, 200):
+            torch.manual_seed(s)
+            nz = torch.rand(1, 5120)
+            if tie_free(nz):
+                seedL = s; break
+        with torch.no_grad():
+            lossL, predL, maskL = run_reference(modelL, imgsL, seedL, 0.75)
+        torch.manual_seed(seedL)
+        _, _, irL, ikL = modelL.random_masking(torch.zeros(1, 5120, 1), 0.75)
+        idx = torch.arange(0, 5120 * 768, 39_989)
+        np.savez_compressed(os.path.join(out_dir, "vitl_pins.npz"), loss=lossL.numpy(), noise_seed=seedL,
+                            mask_sum=maskL.sum().numpy(), pred_idx=idx.numpy(),
+                            pred_samples=predL.flatten()[idx].numpy(),
+                            pred_l2=predL.double().norm().numpy(), ids_restore=irL.numpy().astype(np.int32),
+                            n_params=sum(p.numel() for p in modelL.parameters()))
+        print("ViT-L: loss", float(lossL), "mask", float(maskL.sum()), "params",
+              sum(p.numel() for p in modelL.parameters()))
+
+
+if __name__ == "__main__":
+    main()
