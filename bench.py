@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 3-D MAE pre-training volumes/s (ViT-L, 60x256x256 volumes, mask 0.75, bf16) on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            # N = 1: plain python
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W                       # N > 1: one rank per GPU over RCCL
+
+A "step" is one optimizer step over the fixed GLOBAL batch (default 256 volumes, BASELINE config 3): every rank runs
+global_batch / N volumes as micro-batches (default 32) with gradient accumulation, the flat-arena all-reduce overlaps the
+last micro-batch's backward, then grad-norm + fused AdamW.  Strong scaling: total work per step is fixed.
+Inputs are synthetic fp32 volumes already resident in HBM; weights are the reference's random init; masking noise comes
+from the device RNG inside the timed region.  Rank 0 prints ONE JSON line.
+
+The line also carries
+  roofline     -- the dominant kernel of the timed region (by summed device time, measured with HIP events recorded on the
+                  launch stream around every MFMA kernel launch): algorithmic FLOP / measured time vs the dense bf16 MFMA peak
+  cpu_baseline -- the CPU oracle (oracle/mae3d_ref.py, a port of the reference's non-flash model) timed on this host's
+                  cores for ONE volume forward+backward (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+FWD_GFLOP_PER_VOLUME = 1636.0  # BASELINE.md §3 (algorithmic, multiply-add = 2)
+
+
+def cpu_baseline(max_seconds_hint=60.0):
+    """One ViT-L volume forward+backward through the CPU oracle on all host cores."""
+    from oracle import mae3d_ref as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = O.init_params(O.VIT_L, seed=0)
+    imgs = torch.rand(1, 1, 60, 256, 256, generator=torch.Generator().manual_seed(0))
+    noise = torch.rand(1, 5120, generator=torch.Generator().manual_seed(1))
+    t0 = time.time()
+    loss, _, _, _, _ = O.forward_backward(P, imgs, O.VIT_L, 0.75, noise)
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "volumes/s", "cores": cores, "kind": "port",
+            "sample": f"1 volume (1x60x256x256) forward+backward, fp32, torch CPU {cores} threads, {dt:.1f} s, loss {float(loss):.4f}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--global-batch", type=int, default=256)
+    ap.add_argument("--micro-batch", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--clip-grad", type=float, default=None)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    from octcubem_amd import models_mae, misc, ops, optim as foptim
+    from octcubem_amd.parallel import FlatGradReducer
+
+    assert args.global_batch % world == 0
+    per_rank = args.global_batch // world
+    mb = min(args.micro_batch, per_rank)
+    assert per_rank % mb == 0
+    accum = per_rank // mb
+
+    torch.manual_seed(0)                                   # identical initial weights on every rank
+    model = models_mae.octcube_vit_large_3dmae().to(dev)
+    model.train()
+    reducer = FlatGradReducer(model) if world > 1 else None
+    model.prepare()
+    if reducer is not None:
+        reducer.broadcast_parameters(0)
+    opt = foptim.FusedAdamW(misc.add_weight_decay(model, 0.05), lr=1.6e-3 * args.global_batch / 256, betas=(0.9, 0.95))
+    scaler = misc.NativeScalerWithGradNormCount(fp32=True, reducer=reducer)
+    params = list(model.parameters())
+
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)   # rank r sees different volumes (seed + rank, main_pretrain…:306)
+    pool = [torch.rand(mb, 1, 60, 256, 256, device=dev, generator=g) for _ in range(min(accum, 2))]
+
+    def step():
+        opt.zero_grad()
+        last = None
+        for i in range(accum):
+            loss, _, _ = model(pool[i % len(pool)], mask_ratio=0.75)
+            last = loss
+            scaler(loss / accum, opt, parameters=params, update_grad=(i == accum - 1), clip_grad=args.clip_grad)
+        return last
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_kernel_timing:
+        ops.KTIMER = ops.KernelTimer()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    kt = ops.KTIMER.summary() if ops.KTIMER is not None else {}
+    ops.KTIMER = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_value = float(loss)
+
+    if rank == 0:
+        vps = args.steps * args.global_batch / dt
+        out = {
+            "metric": "3D-MAE pretrain volumes/s (ViT-L, 60x256x256, mask 0.75)", "value": vps, "unit": "volumes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "OCTCube ViT-L 3D-MAE pre-train step (fwd+bwd+all-reduce+AdamW), synthetic (1,60,256,256) volumes, "
+                                   "mask_ratio 0.75, decoder 512x8x16", "global_batch": args.global_batch,
+                       "micro_batch_per_gpu": mb, "accum_steps": accum, "tokens_enc_dec": [1281, 5121],
+                       "parallelism": f"dp{world}"},
+            "loss": loss_value,
+            "model_tflops_per_s": vps * 3 * FWD_GFLOP_PER_VOLUME / 1e3,
+            "mfu_vs_dense_bf16_peak": vps * 3 * FWD_GFLOP_PER_VOLUME / 1e3 / (PEAK_BF16_TFLOPS * world),
+        }
+        if kt:
+            tot = sum(v["total_ms"] for v in kt.values())
+            dom = max(kt, key=lambda k: kt[k]["total_ms"])
+            d = kt[dom]
+            ach = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "avg_launch_us": d["avg_us"],
+                               "launches": d["launches"], "share_of_timed_mfma_kernels": d["total_ms"] / tot}
+            out["kernels"] = {k: {"ms": round(v["total_ms"], 3), "avg_us": round(v["avg_us"], 2), "launches": v["launches"],
+                                  "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1)} for k, v in sorted(kt.items())}
+            att = [k for k in kt if k.startswith("attn_")]
+            if att:
+                fl = sum(kt[k]["flops"] for k in att); ms = sum(kt[k]["total_ms"] for k in att)
+                out["attention_qk_pv"] = {"tflops": fl / (ms * 1e-3) / 1e12, "frac_of_bf16_peak": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                                          "ms": ms}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the GPU number must survive a host that cannot fit the oracle
+                out["cpu_baseline"] = {"value": None, "unit": "volumes/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+/* liboctmae -- C ABI of the MI355X-native 3-D MAE hot path (gfx950 only).
+ *
+ * The reference (ZucksLiu/OCTCubeM) has no FFI layer: every GPU operation it performs arrives through
+ * PyTorch/ATen, cuDNN/cuBLAS and flash-attn from Python modules.  These entry points are what a binding
+ * for that path binds instead; each one names the reference call site it replaces (paths relative to
+ * /root/reference).  The Python host side (octcubem_amd/_lib.py, ctypes) is the only caller.
+ *
+ * Conventions
+ *   - plain pointers and sizes, no torch types; all pointers are DEVICE pointers unless noted
+ *   - the caller owns every buffer (incl. workspaces); nothing is allocated or retained by the library
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*); no host synchronisation
+ *   - return value: 0 ok, <0 argument error (-1 bad argument, -2 unsupported combination), >0 hipError_t
+ *   - "bf16" buffers are raw 16-bit bfloat16 values; row-major; leading dimensions in ELEMENTS
+ *   - re-entrant, no thread-local state: forward runs on the main thread, backward on autograd's thread
+ */
+#ifndef OCTMAE_H_
+#define OCTMAE_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int octmae_abi_version(void);
+
+/* ---- GEMM with fused epilogues ------------------------------------------------------------------
+ * X[a][b] = sum_k A[a][k] * B[b][k],  A has NA rows, B has NB rows, reduction length K.
+ * a_kstrided / b_kstrided = 0: operand stored [rows][K] (nn.Linear layout); 1: stored [K][rows].
+ * epilogue (output is C[b][a], i.e. NB rows x NA contiguous columns, unless noted):
+ *   0  C bf16 = X + bias[a]                       nn.Linear forward        video_vit.py:114-135, timm Mlp fc1/fc2
+ *   1  C f32  = X + bias[a]                       decoder_pred             models_mae_joint_res_flash_attn.py:595
+ *   2  C bf16 = X + bias, C2 bf16 = gelu(C)       Mlp fc1 + nn.GELU        video_vit.py:174-179 (timm Mlp)
+ *   3  C f32  = aux_f32[b][a] + X + bias[a]       proj / fc2 + residual    video_vit.py:182-183
+ *   4  C bf16 = X * gelu'(aux_bf16[b][a])         backward of 2 (dgrad of fc2 fused with GELU')
+ *   5  C f32[a][b] += X  (NA rows x NB columns; split-K over `splitk` workgroup slices, fp32 atomics
+ *                         when splitk > 1)        weight gradients (autograd of nn.Linear)
+ * bias may be NULL.  Requirements: lda, ldb multiples of 8; NA multiple of 4 (epilogues 0-4). */
+int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
+                     int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided, int b_kstrided,
+                     int epilogue, int splitk, void* stream);
+
+/* ---- LayerNorm over the fp32 residual stream ---------------------------------------------------
+ * nn.LayerNorm(eps=1e-6): models_mae_joint_res_flash_attn.py:799, video_vit.py:161,172,181-184, :489, :592.
+ * fwd: y bf16 = (x - mean) * rstd * gamma + beta; saves mean, rstd (fp32 [M]).
+ * bwd: dx f32 = (dres ? dres : 0) + LN'(dy); optional bf16 copy of dx; dgamma/dbeta/dxsum (column sums of
+ *      dx = bias gradient of the preceding Linear) are ACCUMULATED (+=) when non-NULL.  D % 4 == 0, D <= 2048. */
+int octmae_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean, float* rstd,
+                         int M, int D, float eps, void* stream);
+int octmae_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* gamma,
+                         const float* dres, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* dxsum, int M,
+                         int D, void* stream);
+
+/* ---- attention -----------------------------------------------------------------------------------
+ * softmax(q k^T * scale) v, non-causal, no dropout: video_vit.py:130-134 (flash path: flash_attn MHA,
+ * models_mae_joint_res_flash_attn.py:131-149).  qkv bf16 [B][N][3][H][HD]; o, dout bf16 [B][N][H][HD];
+ * lse f32 [B][H][N] (natural log); delta_ws f32 [B][H][N] workspace; dqkv bf16 like qkv.  HD in {32, 64}. */
+int octmae_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int HD, float scale, void* stream);
+int octmae_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta_ws, void* dqkv, int B,
+                    int N, int H, int HD, float scale, void* stream);
+/* the three launches octmae_attn_bwd is made of (delta = rowsum(dO * O); dQ; dK and dV), callable one by one */
+int octmae_attn_bwd_delta(const void* o, const void* dout, float* delta, int B, int N, int H, int HD, void* stream);
+int octmae_attn_bwd_dq(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int N, int H,
+                       int HD, float scale, void* stream);
+int octmae_attn_bwd_dkv(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int N, int H,
+                        int HD, float scale, void* stream);
+
+/* ---- random masking indices ---------------------------------------------------------------------
+ * MaskedAutoencoderViT.random_masking index part, models_mae_joint_res_flash_attn.py:349-369:
+ * ids_shuffle = argsort(noise) with ties -> lower index, ids_restore = its inverse, ids_keep = first len_keep,
+ * mask = 0 keep / 1 remove in original order.  int64 outputs (torch index dtype).  ids_shuffle may be NULL.
+ * L <= 16384. */
+int octmae_random_masking_ids(const float* noise, long long* ids_restore, long long* ids_keep, long long* ids_shuffle,
+                              float* mask, int B, int L, int len_keep, void* stream);
+
+/* ---- token plumbing ------------------------------------------------------------------------------ */
+int octmae_cast_f32_bf16(const float* src, void* dst_bf16, long long n, void* stream);
+/* out[c] += sum_r in[r][c]  (nn.Linear bias gradient) */
+int octmae_colsum_accum(const void* in, int in_is_bf16, float* out, int M, int N, int ld, void* stream);
+/* im2col of the kept tokens for PatchEmbed's Conv3d(k = s = (tp,p,p)), video_vit.py:70-83 + the gather at
+ * models_mae_joint_res_flash_attn.py:363: out bf16 [B*nkeep][C*tp*p*p] in conv-weight order (c,u,py,px).
+ * ids: [B][nkeep] int64 (ids_is_i64=1) or int32, NULL = tokens 0..nkeep-1. */
+int octmae_patch_gather(const float* imgs, const void* ids, int ids_is_i64, void* out_bf16, int B, int C, int T, int H,
+                        int W, int tp, int p, int nkeep, void* stream);
+/* encoder input: cls concat + gathered sep pos-embed add, models_mae_joint_res_flash_attn.py:409-478 */
+int octmae_enc_assemble(const void* tok_bf16, const float* pos, const float* cls, const float* pos_cls,
+                        const long long* ids_keep, float* x, int B, int nkeep, int D, void* stream);
+/* decoder input: mask tokens + un-shuffle + cls + pos-embed, models_mae_joint_res_flash_attn.py:515-573 */
+int octmae_dec_assemble(const void* emb_bf16, const float* mask_token, const float* dpos, const float* dcls,
+                        const float* dpos_cls, const long long* ids_restore, float* x, int B, int nkeep, int L, int D,
+                        void* stream);
+/* out bf16[b*n+i][:] = src f32[b][1+ids[b][i]][:]  (backward of both assemblies w.r.t. the token rows) */
+int octmae_gather_rows_cast(const float* src, const long long* ids, void* out_bf16, int B, int n, int src_rows, int D,
+                            void* stream);
+/* fused patchify + per-token MSE, models_mae_joint_res_flash_attn.py:289-314, :613-650.  pred f32 [B][L+1][PD]
+ * (row 0 = cls, ignored); loss_tok f32 [B][L].  frame_idx int32 [pred_t_dim] or NULL (identity). */
+int octmae_mse_fwd(const float* pred, const float* imgs, const int* frame_idx, float* loss_tok, int B, int C, int T, int H,
+                   int W, int u_sz, int p, int L, int norm_pix, void* stream);
+/* dpred bf16 [B][L+1][PD] = *coef * mask * (pred - target), cls rows zero (backward of :649-663) */
+int octmae_mse_bwd(const float* pred, const float* imgs, const int* frame_idx, const float* mask, const float* coef,
+                   void* dpred_bf16, int B, int C, int T, int H, int W, int u_sz, int p, int L, int norm_pix, void* stream);
+
+/* ---- optimizer side --------------------------------------------------------------------------------
+ * Multi-tensor tables: tensor_table = device array of {float* p, g, m, v; int64 n}; chunk_tensor/chunk_off map
+ * each chunk of octmae_mt_chunk_elems() elements to (tensor, element offset).
+ * get_grad_norm_ / clip_grad_norm_: custom_util/misc.py:328-336, :356-373.  AdamW: main_pretrain_oph_joint_2d512_flash_attn.py:451. */
+int octmae_mt_chunk_elems(void);
+int octmae_mt_sumsq(const void* tensor_table, const int* chunk_tensor, const long long* chunk_off, int nchunks, float* sumsq,
+                    void* stream);
+int octmae_mt_finish_norm(const float* sumsq, int ntensors, float max_norm, float* out_norm, float* out_coef, void* stream);
+int octmae_mt_adamw(const void* tensor_table, const int* chunk_tensor, const long long* chunk_off, int nchunks,
+                    const float* gscale, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                    void* stream);
+
+/* ---- hardware layout probes (tests only: pin the MFMA / ds_read_b64_tr_b16 lane maps the kernels assume) */
+int octmae_probe_mfma32(const void* a_frag_bf16, const void* b_frag_bf16, float* d_regs, void* stream);
+int octmae_probe_trread(const void* tile_bf16_16x16, void* out_bf16, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCTMAE_H_ */

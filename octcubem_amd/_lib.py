@@ -1,0 +1,78 @@
+"""ctypes binding of liboctmae.so (the C ABI declared in include/octmae.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent the import of any
+compute entry point raises.  PyTorch is used only for device memory, streams and autograd plumbing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboctmae.so")
+
+_vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+# name -> argtypes ; every function returns int (0 ok, <0 bad argument, >0 hipError_t)
+SIGNATURES = {
+    "octmae_abi_version": [],
+    "octmae_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "octmae_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "octmae_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "octmae_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "octmae_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "octmae_attn_bwd_delta": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "octmae_attn_bwd_dq": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "octmae_attn_bwd_dkv": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "octmae_random_masking_ids": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "octmae_cast_f32_bf16": [_vp, _vp, _ll, _vp],
+    "octmae_colsum_accum": [_vp, _i, _vp, _i, _i, _i, _vp],
+    "octmae_patch_gather": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "octmae_enc_assemble": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "octmae_dec_assemble": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "octmae_gather_rows_cast": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "octmae_mse_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "octmae_mse_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "octmae_mt_chunk_elems": [],
+    "octmae_mt_sumsq": [_vp, _vp, _vp, _i, _vp, _vp],
+    "octmae_mt_finish_norm": [_vp, _i, _f, _vp, _vp, _vp],
+    "octmae_mt_adamw": [_vp, _vp, _vp, _i, _vp, _f, _f, _f, _f, _f, _i, _vp],
+    "octmae_probe_mfma32": [_vp, _vp, _vp, _vp],
+    "octmae_probe_trread": [_vp, _vp, _vp],
+}
+
+_lib = None
+
+
+class OctmaeError(RuntimeError):
+    pass
+
+
+def load():
+    """Load liboctmae.so and bind every declared symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OctmaeError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C octcubem_amd/csrc).  There is no CPU or eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise OctmaeError(f"liboctmae.so does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke a C-ABI entry point and turn its status code into an exception."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        kind = "bad argument" if rc == -1 else "unsupported combination" if rc == -2 else f"hipError_t {rc}"
+        raise OctmaeError(f"{name} failed: {kind} (rc={rc})")
+    return rc

@@ -1,0 +1,575 @@
+// Flash-style non-causal attention forward / backward for gfx950, head_dim 64 (encoder) and 32 (decoder),
+// arbitrary sequence length (1281 and 5121 are both 1 mod 64).  Replaces the reference's
+// softmax((q k^T) * hd^-0.5) v  (Pre-training/custom_util/video_vit.py:130-134; flash path: flash-attn MHA
+// built at models_mae_joint_res_flash_attn.py:131-149) without materialising the (B,H,N,N) scores.
+//
+// Layout: qkv bf16 [B][N][3][H][HD] (the fused Wqkv GEMM output), o bf16 [B][N][H][HD], lse fp32 [B][H][N].
+//
+// MFMA orientation (v_mfma_f32_32x32x16_bf16; D register g = row (g&3)+8(g>>2)+4h, lane&31 = column):
+//   S^T[key][query] = K . Q^T        keys on the registers, the QUERY ON THE LANE: the softmax row
+//                                    reduction is over a lane's own registers plus one exchange with
+//                                    lane^32 -- no LDS, no 32-lane shuffles.
+//   O^T[d][query]  += V^T . P^T      P^T is the previous accumulator re-used as the B operand with no lane
+//                                    movement (registers 8s..8s+7 -> k-step s); V^T comes from the row-major V
+//                                    tile in LDS through ds_read_b64_tr_b16.
+// Backward is two deterministic kernels (no atomics): dQ walks key tiles with the same orientation; dK/dV
+// keeps the KEY on the lane and walks query tiles, so dK^T/dV^T accumulate in registers.
+// K/V (or Q/dO) tiles are 64 rows, register-staged, double-buffered in LDS with one barrier per tile; the
+// XOR swizzle makes both the ds_read_b128 row reads and the transposed reads bank-conflict-free.
+#include "common.hpp"
+#include "../../include/octmae.h"
+
+namespace octmae {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+template <int HD>
+struct Tile {  // 64 rows x HD bf16, row-major, XOR-swizzled 16-byte chunks
+  static constexpr int ROWB = HD * 2;
+  static constexpr int BYTES = 64 * ROWB;
+  static constexpr int CHUNKS = HD / 8;
+  __device__ static __forceinline__ int sw(int row) {
+    if (HD == 64) return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+    return (row >> 2) & 3;
+  }
+  __device__ static __forceinline__ int off(int row, int c) { return row * ROWB + ((c ^ sw(row)) << 4); }
+
+  // A-operand fragment, rows on the MFMA row index: element j = T[rb + r][16 s + 8 h + j]
+  __device__ static __forceinline__ bf16x8 row_frag(const char* t, int rb, int s, int lane) {
+    return *reinterpret_cast<const bf16x8*>(t + off(rb + (lane & 31), 2 * s + (lane >> 5)));
+  }
+  // A-operand fragment of T^T matching an accumulator-derived B operand (k order of a 32x32 accumulator):
+  // element j = T[kb + 16 s + 8 (j>>2) + 4 h + (j&3)][db + r]
+  __device__ static __forceinline__ bf16x8 tr_frag(const char* t, int kb, int s, int db, int lane) {
+    const int h = lane >> 5, gi = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+    const int c = (db >> 3) + 2 * gi + (p >> 1);
+    const int r0 = kb + 16 * s + 4 * h + q;
+    const bf16x4 lo = lds_tr_read(t + off(r0, c) + (p & 1) * 8);
+    const bf16x4 hi = lds_tr_read(t + off(r0 + 8, c) + (p & 1) * 8);
+    return cat4(lo, hi);
+  }
+};
+
+// register-staged copy of a 64-row tile: rows row0.. of a [.., stride] bf16 matrix, rows >= nvalid zero-filled
+template <int HD>
+struct TileStage {
+  static constexpr int PER = (64 * HD / 8) / 256;  // 16-byte chunks per thread (2 for HD 64, 1 for HD 32)
+  u32x4 regs[PER];
+  __device__ __forceinline__ void issue(const bf16_t* base, size_t stride, int row0, int nvalid, int tid) {
+#pragma unroll
+    for (int n = 0; n < PER; ++n) {
+      const int q = tid + 256 * n;
+      const int r = q / Tile<HD>::CHUNKS, c = q % Tile<HD>::CHUNKS;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row0 + r < nvalid) v = *reinterpret_cast<const u32x4*>(base + (size_t)(row0 + r) * stride + c * 8);
+      regs[n] = v;
+    }
+  }
+  __device__ __forceinline__ void commit(char* lds, int tid) const {
+#pragma unroll
+    for (int n = 0; n < PER; ++n) {
+      const int q = tid + 256 * n;
+      *reinterpret_cast<u32x4*>(lds + Tile<HD>::off(q / Tile<HD>::CHUNKS, q % Tile<HD>::CHUNKS)) = regs[n];
+    }
+  }
+};
+
+// accumulator registers 8s..8s+7 -> bf16 B-operand fragment of k-step s
+__device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int s) {
+  u32x4 w;
+  w[0] = pack2bf(a[8 * s + 0], a[8 * s + 1]);
+  w[1] = pack2bf(a[8 * s + 2], a[8 * s + 3]);
+  w[2] = pack2bf(a[8 * s + 4], a[8 * s + 5]);
+  w[3] = pack2bf(a[8 * s + 6], a[8 * s + 7]);
+  return __builtin_bit_cast(bf16x8, w);
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// =====================================================================================================
+// forward
+// =====================================================================================================
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                          float* __restrict__ lse, int N, int H, float scale) {
+  constexpr int KS = HD / 16;   // k-steps over the head dimension
+  constexpr int DB = HD / 32;   // 32-wide blocks of the head dimension
+  using T = Tile<HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // LDS: K0 K1 V0 V1
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const size_t rs = (size_t)3 * H * HD;
+  const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)head * HD;
+  const bf16_t* kb_ = qb + (size_t)H * HD;
+  const bf16_t* vb_ = qb + (size_t)2 * H * HD;
+  const int q0 = blockIdx.x * 128 + wid * 32;
+  const int qrow = q0 + r;
+
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (qrow < N) v = *reinterpret_cast<const u32x4*>(qb + (size_t)qrow * rs + 16 * s + 8 * h);
+    qf[s] = __builtin_bit_cast(bf16x8, v);
+  }
+
+  f32x16 oacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) oacc[d][g] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sc2 = scale * LOG2E;
+
+  const int ntiles = (N + 63) / 64;
+  TileStage<HD> sk, sv;
+  sk.issue(kb_, rs, 0, N, tid);
+  sv.issue(vb_, rs, 0, N, tid);
+  sk.commit(smem, tid);
+  sv.commit((smem + 2 * T::BYTES), tid);
+  if (ntiles > 1) {
+    sk.issue(kb_, rs, 64, N, tid);
+    sv.issue(vb_, rs, 64, N, tid);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const char* cK = (smem + (t & 1) * T::BYTES);
+    const char* cV = (smem + (2 + (t & 1)) * T::BYTES);
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) sacc[kb][g] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) sacc[kb] = mfma32(T::row_frag(cK, kb * 32, s, lane), qf[s], sacc[kb]);
+    }
+    // scores in the log2 domain; mask the key tail of the last tile
+    const bool tail = (t == ntiles - 1) && (N & 63);
+    float m_loc = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        float v = sacc[kb][g] * sc2;
+        if (tail) {
+          const int key = t * 64 + kb * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+          if (key >= N) v = -INFINITY;
+        }
+        sacc[kb][g] = v;
+        m_loc = fmaxf(m_loc, v);
+      }
+    m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 32, 64));
+    const float m_new = fmaxf(m_run, m_loc);
+    const float alpha = fast_exp2(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const float p = fast_exp2(sacc[kb][g] - m_new);
+        sacc[kb][g] = p;
+        psum += p;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) oacc[d][g] *= alpha;
+    // O^T += V^T P^T
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pf = acc_to_frag(sacc[kb], s);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) oacc[d] = mfma32(T::tr_frag(cV, kb * 32, s, d * 32, lane), pf, oacc[d]);
+      }
+    if (t + 1 < ntiles) {
+      sk.commit((smem + ((t + 1) & 1) * T::BYTES), tid);
+      sv.commit((smem + (2 + ((t + 1) & 1)) * T::BYTES), tid);
+      if (t + 2 < ntiles) {
+        sk.issue(kb_, rs, (t + 2) * 64, N, tid);
+        sv.issue(vb_, rs, (t + 2) * 64, N, tid);
+      }
+    }
+    __syncthreads();
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (qrow < N) {
+    bf16_t* orow = o + ((size_t)b * N + qrow) * (size_t)(H * HD) + (size_t)head * HD;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 w = {pack2bf(oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv),
+                   pack2bf(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv)};
+        *reinterpret_cast<u32x2*>(orow + d * 32 + 8 * g + 4 * h) = w;
+      }
+    if (h == 0) lse[((size_t)b * H + head) * N + qrow] = (m_run + __builtin_amdgcn_logf(l_tot)) * LN2;
+  }
+}
+
+// =====================================================================================================
+// backward pre-pass: delta[b][h][q] = sum_d dO[q][h][d] * O[q][h][d]
+// =====================================================================================================
+template <int HD>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                         float* __restrict__ delta, int BN, int N, int H) {
+  constexpr int LPH = HD / 8;  // lanes per head
+  const int lane = threadIdx.x & 63;
+  const int nwaves = gridDim.x * 4;
+  const int D = H * HD, nchunk = D / 8;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < BN; row += nwaves) {
+    const int b = row / N, q = row % N;
+    for (int c0 = 0; c0 < nchunk; c0 += 64) {
+      const int c = c0 + lane;
+      float s = 0.f;
+      if (c < nchunk) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(o + (size_t)row * D + 8 * c);
+        const u32x4 d = *reinterpret_cast<const u32x4*>(dout + (size_t)row * D + 8 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += bflo(a[e]) * bflo(d[e]) + bfhi(a[e]) * bfhi(d[e]);
+      }
+#pragma unroll
+      for (int m = 1; m < LPH; m <<= 1) s += __shfl_xor(s, m, 64);
+      if (c < nchunk && (lane % LPH) == 0) delta[((size_t)b * H + c / LPH) * N + q] = s;
+    }
+  }
+}
+
+// =====================================================================================================
+// backward dQ: same orientation as forward, queries on the lane, walks key tiles
+//   S^T = K Q^T ; P^T = exp(S^T*scale - lse) ; dP^T = V dO^T ; dS^T = P^T (dP^T - delta) * scale
+//   dQ^T[d][query] += K^T[d][key] dS^T[key][query]
+// =====================================================================================================
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                             const float* __restrict__ lse, const float* __restrict__ delta,
+                                                             bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+  constexpr int KS = HD / 16, DB = HD / 32;
+  using T = Tile<HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // LDS: K0 K1 V0 V1
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const size_t rs = (size_t)3 * H * HD;
+  const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)head * HD;
+  const bf16_t* kb_ = qb + (size_t)H * HD;
+  const bf16_t* vb_ = qb + (size_t)2 * H * HD;
+  const int qrow = blockIdx.x * 128 + wid * 32 + r;
+  const size_t ostride = (size_t)H * HD;
+
+  bf16x8 qf[KS], dof[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u};
+    if (qrow < N) {
+      v = *reinterpret_cast<const u32x4*>(qb + (size_t)qrow * rs + 16 * s + 8 * h);
+      w = *reinterpret_cast<const u32x4*>(dout + ((size_t)b * N + qrow) * ostride + (size_t)head * HD + 16 * s + 8 * h);
+    }
+    qf[s] = __builtin_bit_cast(bf16x8, v);
+    dof[s] = __builtin_bit_cast(bf16x8, w);
+  }
+  float lse2 = 0.f, dlt = 0.f;
+  if (qrow < N) {
+    lse2 = lse[((size_t)b * H + head) * N + qrow] * LOG2E;
+    dlt = delta[((size_t)b * H + head) * N + qrow];
+  }
+  const float sc2 = scale * LOG2E;
+
+  f32x16 dq[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) dq[d][g] = 0.f;
+
+  const int ntiles = (N + 63) / 64;
+  TileStage<HD> sk, sv;
+  sk.issue(kb_, rs, 0, N, tid);
+  sv.issue(vb_, rs, 0, N, tid);
+  sk.commit(smem, tid);
+  sv.commit((smem + 2 * T::BYTES), tid);
+  if (ntiles > 1) {
+    sk.issue(kb_, rs, 64, N, tid);
+    sv.issue(vb_, rs, 64, N, tid);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const char* cK = (smem + (t & 1) * T::BYTES);
+    const char* cV = (smem + (2 + (t & 1)) * T::BYTES);
+    const bool tail = (t == ntiles - 1) && (N & 63);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 sa, dp;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) { sa[g] = 0.f; dp[g] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) sa = mfma32(T::row_frag(cK, kb * 32, s, lane), qf[s], sa);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) dp = mfma32(T::row_frag(cV, kb * 32, s, lane), dof[s], dp);
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        float p = fast_exp2(fmaf(sa[g], sc2, -lse2));
+        if (tail) {
+          const int key = t * 64 + kb * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+          if (key >= N) p = 0.f;
+        }
+        sa[g] = p * (dp[g] - dlt) * scale;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 dsf = acc_to_frag(sa, s);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) dq[d] = mfma32(T::tr_frag(cK, kb * 32, s, d * 32, lane), dsf, dq[d]);
+      }
+    }
+    if (t + 1 < ntiles) {
+      sk.commit((smem + ((t + 1) & 1) * T::BYTES), tid);
+      sv.commit((smem + (2 + ((t + 1) & 1)) * T::BYTES), tid);
+      if (t + 2 < ntiles) {
+        sk.issue(kb_, rs, (t + 2) * 64, N, tid);
+        sv.issue(vb_, rs, (t + 2) * 64, N, tid);
+      }
+    }
+    __syncthreads();
+  }
+  if (qrow < N) {
+    bf16_t* drow = dqkv + ((size_t)b * N + qrow) * rs + (size_t)head * HD;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 w = {pack2bf(dq[d][4 * g], dq[d][4 * g + 1]), pack2bf(dq[d][4 * g + 2], dq[d][4 * g + 3])};
+        *reinterpret_cast<u32x2*>(drow + d * 32 + 8 * g + 4 * h) = w;
+      }
+  }
+}
+
+// =====================================================================================================
+// backward dK/dV: keys on the lane (32 per wave, 128 per block), walks 64-query tiles of Q and dO
+//   S = Q K^T - lse/scale (row constant as the initial accumulator) ; P = exp2(S*scale*log2e)
+//   dV^T[d][key] += dO^T[d][query] P[query][key]
+//   dP = dO V^T - delta ; dS = P dP scale ; dK^T[d][key] += Q^T[d][query] dS[query][key]
+// =====================================================================================================
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+  constexpr int KS = HD / 16, DB = HD / 32;
+  using T = Tile<HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // LDS: Q0 Q1 O0 O1
+  float* ldsC = reinterpret_cast<float*>(smem + 4 * T::BYTES);  // [2 buffers][2: -lse/scale, -delta][64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const size_t rs = (size_t)3 * H * HD;
+  const size_t ostride = (size_t)H * HD;
+  const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)head * HD;
+  const bf16_t* kb_ = qb + (size_t)H * HD;
+  const bf16_t* vb_ = qb + (size_t)2 * H * HD;
+  const bf16_t* dob = dout + (size_t)b * N * ostride + (size_t)head * HD;
+  const float* lse_b = lse + ((size_t)b * H + head) * N;
+  const float* dlt_b = delta + ((size_t)b * H + head) * N;
+  const int krow = blockIdx.x * 128 + wid * 32 + r;
+
+  bf16x8 kf[KS], vf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u};
+    if (krow < N) {
+      v = *reinterpret_cast<const u32x4*>(kb_ + (size_t)krow * rs + 16 * s + 8 * h);
+      w = *reinterpret_cast<const u32x4*>(vb_ + (size_t)krow * rs + 16 * s + 8 * h);
+    }
+    kf[s] = __builtin_bit_cast(bf16x8, v);
+    vf[s] = __builtin_bit_cast(bf16x8, w);
+  }
+  const float sc2 = scale * LOG2E;
+  const float inv_scale = 1.0f / scale;
+
+  f32x16 dk[DB], dv[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { dk[d][g] = 0.f; dv[d][g] = 0.f; }
+
+  const int ntiles = (N + 63) / 64;
+  TileStage<HD> sq, so;
+  float c_lse = 0.f, c_dlt = 0.f;  // threads 0..63 stage the row constants of one tile
+  auto issue_consts = [&](int row0) {
+    if (tid < 64) {
+      const int q = row0 + tid;
+      c_lse = (q < N) ? -lse_b[q] * inv_scale : 0.f;
+      c_dlt = (q < N) ? -dlt_b[q] : 0.f;
+    }
+  };
+  auto commit_consts = [&](int buf) {
+    if (tid < 64) {
+      ldsC[buf * 128 + tid] = c_lse;
+      ldsC[buf * 128 + 64 + tid] = c_dlt;
+    }
+  };
+  sq.issue(qb, rs, 0, N, tid);
+  so.issue(dob, ostride, 0, N, tid);
+  issue_consts(0);
+  sq.commit(smem, tid);
+  so.commit((smem + 2 * T::BYTES), tid);
+  commit_consts(0);
+  if (ntiles > 1) {
+    sq.issue(qb, rs, 64, N, tid);
+    so.issue(dob, ostride, 64, N, tid);
+    issue_consts(64);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const char* cQ = (smem + (t & 1) * T::BYTES);
+    const char* cO = (smem + (2 + (t & 1)) * T::BYTES);
+    const float* cC = ldsC + (t & 1) * 128;
+#pragma unroll
+    for (int qb32 = 0; qb32 < 2; ++qb32) {
+      f32x16 sa, dp;
+      // row constants: register 4G+e <-> query row qb32*32 + 8G + 4h + e
+#pragma unroll
+      for (int G = 0; G < 4; ++G) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(cC + qb32 * 32 + 8 * G + 4 * h);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(cC + 64 + qb32 * 32 + 8 * G + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sa[4 * G + e] = a[e]; dp[4 * G + e] = d[e]; }
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) sa = mfma32(T::row_frag(cQ, qb32 * 32, s, lane), kf[s], sa);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) dp = mfma32(T::row_frag(cO, qb32 * 32, s, lane), vf[s], dp);
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const float p = fast_exp2(sa[g] * sc2);
+        sa[g] = p;
+        dp[g] = p * dp[g] * scale;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pf = acc_to_frag(sa, s);
+        const bf16x8 dsf = acc_to_frag(dp, s);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          dv[d] = mfma32(T::tr_frag(cO, qb32 * 32, s, d * 32, lane), pf, dv[d]);
+          dk[d] = mfma32(T::tr_frag(cQ, qb32 * 32, s, d * 32, lane), dsf, dk[d]);
+        }
+      }
+    }
+    if (t + 1 < ntiles) {
+      sq.commit((smem + ((t + 1) & 1) * T::BYTES), tid);
+      so.commit((smem + (2 + ((t + 1) & 1)) * T::BYTES), tid);
+      commit_consts((t + 1) & 1);
+      if (t + 2 < ntiles) {
+        sq.issue(qb, rs, (t + 2) * 64, N, tid);
+        so.issue(dob, ostride, (t + 2) * 64, N, tid);
+        issue_consts((t + 2) * 64);
+      }
+    }
+    __syncthreads();
+  }
+  if (krow < N) {
+    bf16_t* drow = dqkv + ((size_t)b * N + krow) * rs + (size_t)head * HD;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 wk = {pack2bf(dk[d][4 * g], dk[d][4 * g + 1]), pack2bf(dk[d][4 * g + 2], dk[d][4 * g + 3])};
+        u32x2 wv = {pack2bf(dv[d][4 * g], dv[d][4 * g + 1]), pack2bf(dv[d][4 * g + 2], dv[d][4 * g + 3])};
+        *reinterpret_cast<u32x2*>(drow + (size_t)H * HD + d * 32 + 8 * g + 4 * h) = wk;
+        *reinterpret_cast<u32x2*>(drow + (size_t)2 * H * HD + d * 32 + 8 * g + 4 * h) = wv;
+      }
+  }
+}
+
+template <int HD>
+static int run_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, int H, float scale, hipStream_t st) {
+  const int lds = 4 * Tile<HD>::BYTES;
+  dim3 grid((N + 127) / 128, H, B);
+  hipLaunchKernelGGL(attn_fwd_kernel<HD>, grid, dim3(256), lds, st, qkv, o, lse, N, H, scale);
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int HD>
+static int run_delta(const bf16_t* o, const bf16_t* dout, float* delta, int B, int N, int H, hipStream_t st) {
+  int blocks = (B * N + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3(blocks), dim3(256), 0, st, o, dout, delta, B * N, N, H);
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
+}
+template <int HD>
+static int run_dq(const bf16_t* qkv, const bf16_t* dout, const float* lse, const float* delta, bf16_t* dqkv, int B, int N, int H,
+                  float scale, hipStream_t st) {
+  dim3 grid((N + 127) / 128, H, B);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, grid, dim3(256), 4 * Tile<HD>::BYTES, st, qkv, dout, lse, delta, dqkv, N, H, scale);
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
+}
+template <int HD>
+static int run_dkv(const bf16_t* qkv, const bf16_t* dout, const float* lse, const float* delta, bf16_t* dqkv, int B, int N, int H,
+                   float scale, hipStream_t st) {
+  dim3 grid((N + 127) / 128, H, B);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<HD>, grid, dim3(256), 4 * Tile<HD>::BYTES + 1024, st, qkv, dout, lse, delta, dqkv, N, H,
+                     scale);
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace octmae
+using namespace octmae;
+
+extern "C" int octmae_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int HD, float scale, void* stream) {
+  OCTMAE_CHECK_ARG(qkv && o && lse && B > 0 && N > 0 && H > 0);
+  OCTMAE_CHECK_ARG(HD == 64 || HD == 32);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (HD == 64) return run_fwd<64>(reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<bf16_t*>(o), lse, B, N, H, scale, st);
+  return run_fwd<32>(reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<bf16_t*>(o), lse, B, N, H, scale, st);
+}
+
+#define BFP(x) reinterpret_cast<const bf16_t*>(x)
+extern "C" int octmae_attn_bwd_delta(const void* o, const void* dout, float* delta, int B, int N, int H, int HD, void* stream) {
+  OCTMAE_CHECK_ARG(o && dout && delta && B > 0 && N > 0 && H > 0 && (HD == 64 || HD == 32));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return HD == 64 ? run_delta<64>(BFP(o), BFP(dout), delta, B, N, H, st) : run_delta<32>(BFP(o), BFP(dout), delta, B, N, H, st);
+}
+extern "C" int octmae_attn_bwd_dq(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int N,
+                                  int H, int HD, float scale, void* stream) {
+  OCTMAE_CHECK_ARG(qkv && dout && lse && delta && dqkv && B > 0 && N > 0 && H > 0 && (HD == 64 || HD == 32));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  bf16_t* d = reinterpret_cast<bf16_t*>(dqkv);
+  return HD == 64 ? run_dq<64>(BFP(qkv), BFP(dout), lse, delta, d, B, N, H, scale, st)
+                  : run_dq<32>(BFP(qkv), BFP(dout), lse, delta, d, B, N, H, scale, st);
+}
+extern "C" int octmae_attn_bwd_dkv(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int N,
+                                   int H, int HD, float scale, void* stream) {
+  OCTMAE_CHECK_ARG(qkv && dout && lse && delta && dqkv && B > 0 && N > 0 && H > 0 && (HD == 64 || HD == 32));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  bf16_t* d = reinterpret_cast<bf16_t*>(dqkv);
+  return HD == 64 ? run_dkv<64>(BFP(qkv), BFP(dout), lse, delta, d, B, N, H, scale, st)
+                  : run_dkv<32>(BFP(qkv), BFP(dout), lse, delta, d, B, N, H, scale, st);
+}
+// convenience: the three launches above, in order
+extern "C" int octmae_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta_ws, void* dqkv,
+                               int B, int N, int H, int HD, float scale, void* stream) {
+  int rc = octmae_attn_bwd_delta(o, dout, delta_ws, B, N, H, HD, stream);
+  if (rc) return rc;
+  rc = octmae_attn_bwd_dq(qkv, dout, lse, delta_ws, dqkv, B, N, H, HD, scale, stream);
+  if (rc) return rc;
+  return octmae_attn_bwd_dkv(qkv, dout, lse, delta_ws, dqkv, B, N, H, HD, scale, stream);
+}

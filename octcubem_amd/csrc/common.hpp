@@ -1,0 +1,112 @@
+// Shared device helpers for the gfx950 (MI355X, CDNA4) kernels of the 3-D MAE hot path.
+// wave = 64 lanes everywhere; no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace octmae {
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(2))) short bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// ---- bf16 <-> f32 ---------------------------------------------------------------------------
+// Plain casts: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN).
+__device__ __forceinline__ bf16_t f2bf(float x) {
+  __bf16 h = (__bf16)x;
+  return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) {
+  return __builtin_bit_cast(float, ((uint32_t)h) << 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  f2 v = {lo, hi};
+  bf2 r = __builtin_convertvector(v, bf2);
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ float bflo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bfhi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// ---- wave reductions (64 lanes) -------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- exact-erf GELU (timm Mlp act_layer=nn.GELU), Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7) --
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  float p = 1.061405429f;
+  p = fmaf(p, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __expf(-ax * ax);
+  const float r = 1.0f - p * t * e;
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f));
+}
+// d/dx gelu(x) = Phi(x) + x * phi(x)
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return fmaf(x, pdf, cdf);
+}
+
+// ---- MFMA wrappers ---------------------------------------------------------------------------
+// D(32x32) += A(32x16) * B(16x32).  lane l: r = l & 31, h = l >> 5.
+//   A fragment element j = A[row r][k = 8h + j]      B fragment element j = B[k = 8h + j][col r]
+//   D register g      = D[row (g&3) + 8*(g>>2) + 4h][col r]
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3
+// of a 4x16 block of 16-bit elements; lane i of the group receives column i (rows 0..3).
+__device__ __forceinline__ bf16x4 lds_tr_read(const void* lds_ptr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(lds_ptr));
+}
+
+__device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) {
+  bf16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return r;
+}
+
+// XCD-aware block remap (8 XCDs, round-robin dispatch): blocks that land on one XCD get a contiguous
+// range of logical tile ids, so neighbouring tiles share that XCD's L2.  Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+  const int q = n >> 3, r = n & 7, x = bid & 7, w = bid >> 3;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + w;
+}
+
+}  // namespace octmae
+
+// ---- host-side error plumbing for the C ABI ---------------------------------------------------
+#define OCTMAE_CHECK_ARG(cond) \
+  do {                         \
+    if (!(cond)) return -1;    \
+  } while (0)
+#define OCTMAE_LAUNCH_CHECK()                  \
+  do {                                         \
+    hipError_t e__ = hipGetLastError();        \
+    if (e__ != hipSuccess) return (int)e__;    \
+  } while (0)

@@ -1,0 +1,323 @@
+// bf16 MFMA GEMM for gfx950 with the three operand layouts the transformer needs and fused epilogues.
+//
+//   X[a][b] = sum_k A[a][k] * B[b][k]          (A: NA rows, B: NB rows, reduction K)
+//
+// Each operand is either "k-contiguous" (memory [rows][K], the nn.Linear layout) or "k-strided"
+// (memory [K][rows]); a k-strided tile is staged row-major in LDS and handed to the MFMA through
+// ds_read_b64_tr_b16 (hardware transpose), so no operand is ever transposed in HBM:
+//   forward  y = x W^T      : A = W [N][K] kc,  B = x  [M][K] kc    -> C[M][N]   (reference K6 GEMMs,
+//   dgrad    dx = dy W      : A = W [N][K] ks,  B = dy [M][N] kc    -> C[M][K]    video_vit.py:114-135,
+//   wgrad    dW = dy^T x    : A = dy[M][N] ks,  B = x  [M][K] ks    -> C[N][K]    timm Mlp fc1/fc2)
+// Output orientation: OUT_BA writes C[b][a] (lane = row b, 4 consecutive a per register quad: packed
+// 8/16-byte stores); OUT_AB writes C[a][b] (lane-contiguous 128-B segments: the shape fp32 atomics
+// run at full rate with, used by split-K wgrad).
+//
+// Tile 128(a) x 128(b) x 64(k), 4 waves (2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x16_bf16 tiles,
+// register-staged double-buffered LDS (global loads for tile t+2 are in flight during the MFMAs of tile
+// t; LDS write of tile t+1 after the MFMAs; one barrier per k-tile), XOR-swizzled LDS images that are
+// conflict-free for ds_read_b128 (k-contiguous) and for the transposed reads (k-strided).
+#include "common.hpp"
+#include "../../include/octmae.h"
+
+namespace octmae {
+
+constexpr int TA = 128, TB = 128, TK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // one operand tile, either layout: 16 KiB
+
+enum Epi : int {
+  EPI_BF16 = 0,      // C bf16 = X (+bias[a])
+  EPI_F32 = 1,       // C f32  = X (+bias[a])
+  EPI_GELU = 2,      // C bf16 = X+bias (pre-activation), C2 bf16 = gelu(X+bias)
+  EPI_RESID = 3,     // C f32  = aux_f32 + X + bias
+  EPI_DGELU = 4,     // C bf16 = X * gelu'(aux_bf16)
+  EPI_ACCUM = 5,     // C f32 += X   (OUT_AB; atomics when split-K > 1)
+};
+
+struct GemmParams {
+  const bf16_t* A;
+  const bf16_t* B;
+  void* C;
+  void* C2;
+  const float* bias;
+  const void* aux;
+  int NA, NB, K;
+  int lda, ldb, ldc, ldaux;
+  int tiles_a, tiles_b;
+  int ktiles, ktiles_per_split;
+};
+
+// ---- LDS images ------------------------------------------------------------------------------
+// k-contiguous tile: [128 rows][64 k] bf16, 128-B rows, 16-B chunk c of row r at r*128 + ((c ^ ((r>>1)&7))<<4)
+__device__ __forceinline__ int kc_off(int r, int c) { return r * 128 + (((c ^ ((r >> 1) & 7))) << 4); }
+// k-strided tile: [64 k][128 rows] bf16, 256-B rows, chunk c of k-row kr at kr*256 + ((c ^ ((kr&3)<<2))<<4)
+__device__ __forceinline__ int ks_off(int kr, int c) { return kr * 256 + ((c ^ ((kr & 3) << 2)) << 4); }
+
+template <bool KS>
+struct TileLoader {
+  // each of the 256 threads moves 4 x 16 B of a 16 KiB tile
+  const bf16_t* base;  // operand base
+  int ld;              // leading dimension (elements)
+  int row0;            // first tile row (a or b index)
+  int nrows;           // valid rows of the operand
+  int K;
+  u32x4 regs[4];
+
+  __device__ __forceinline__ void issue(int k0, int tid) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int q = tid + 256 * n;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (!KS) {
+        const int r = q >> 3, c = q & 7;
+        const int gr = row0 + r, gk = k0 + c * 8;
+        if (gr < nrows && gk < K) v = *reinterpret_cast<const u32x4*>(base + (size_t)gr * ld + gk);
+      } else {
+        const int kr = q >> 4, c = q & 15;
+        const int gk = k0 + kr, gr = row0 + c * 8;
+        if (gk < K && gr < nrows) v = *reinterpret_cast<const u32x4*>(base + (size_t)gk * ld + gr);
+      }
+      regs[n] = v;
+    }
+  }
+  __device__ __forceinline__ void commit(char* lds, int tid) const {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int q = tid + 256 * n;
+      int off;
+      if (!KS) off = kc_off(q >> 3, q & 7);
+      else off = ks_off(q >> 4, q & 15);
+      *reinterpret_cast<u32x4*>(lds + off) = regs[n];
+    }
+  }
+};
+
+// fragment of 32 rows starting at rb for k-step s (16 k) of a staged tile
+template <bool KS>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds, int rb, int s, int lane) {
+  if (!KS) {
+    const int r = rb + (lane & 31), c = 2 * s + (lane >> 5);
+    return *reinterpret_cast<const bf16x8*>(lds + kc_off(r, c));
+  } else {
+    const int h = lane >> 5, gi = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+    const int c = (rb >> 3) + 2 * gi + (p >> 1);
+    const int kr0 = 16 * s + 8 * h + q;
+    const bf16x4 lo = lds_tr_read(lds + ks_off(kr0, c) + (p & 1) * 8);
+    const bf16x4 hi = lds_tr_read(lds + ks_off(kr0 + 4, c) + (p & 1) * 8);
+    return cat4(lo, hi);
+  }
+}
+
+template <bool A_KS, bool B_KS, int EPI, bool OUT_AB>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // buffers: A0 A1 B0 B1
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wa = wid >> 1, wb = wid & 1;
+
+  // a-fastest tile order inside an XCD chunk: neighbouring blocks share the B (activation) panel
+  const int nt = p.tiles_a * p.tiles_b;
+  const int t = xcd_remap(blockIdx.x, nt);
+  const int tb = t / p.tiles_a, ta = t - tb * p.tiles_a;
+  const int a0 = ta * TA, b0 = tb * TB;
+
+  const int kt0 = blockIdx.z * p.ktiles_per_split;
+  int kt1 = kt0 + p.ktiles_per_split;
+  if (kt1 > p.ktiles) kt1 = p.ktiles;
+  const int nk = kt1 - kt0;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  TileLoader<A_KS> la{p.A, p.lda, a0, p.NA, p.K, {}};
+  TileLoader<B_KS> lb{p.B, p.ldb, b0, p.NB, p.K, {}};
+
+  if (nk > 0) {
+    la.issue(kt0 * TK, tid);
+    lb.issue(kt0 * TK, tid);
+    la.commit(smem, tid);
+    lb.commit(smem + 2 * TILE_BYTES, tid);
+    if (nk > 1) {
+      la.issue((kt0 + 1) * TK, tid);
+      lb.issue((kt0 + 1) * TK, tid);
+    }
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+      const char* cA = smem + (it & 1) * TILE_BYTES;
+      const char* cB = smem + (2 + (it & 1)) * TILE_BYTES;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bf16x8 fa[2], fb[2];
+        fa[0] = read_frag<A_KS>(cA, wa * 64, s, lane);
+        fa[1] = read_frag<A_KS>(cA, wa * 64 + 32, s, lane);
+        fb[0] = read_frag<B_KS>(cB, wb * 64, s, lane);
+        fb[1] = read_frag<B_KS>(cB, wb * 64 + 32, s, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = mfma32(fa[i], fb[j], acc[i][j]);  // D[a][b]: lane = b, registers = a
+          }
+      }
+      if (it + 1 < nk) {
+        la.commit(smem + ((it + 1) & 1) * TILE_BYTES, tid);
+        lb.commit(smem + (2 + ((it + 1) & 1)) * TILE_BYTES, tid);
+        if (it + 2 < nk) {
+          la.issue((kt0 + it + 2) * TK, tid);
+          lb.issue((kt0 + it + 2) * TK, tid);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+  const int r = lane & 31, h = lane >> 5;
+  if (!OUT_AB) {
+    // acc[i][j] register 4g+e = X[a = a0 + wa*64 + i*32 + 8g + 4h + e][b = b0 + wb*64 + j*32 + r]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int b = b0 + wb * 64 + j * 32 + r;
+      if (b >= p.NB) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int a = a0 + wa * 64 + i * 32 + 8 * g + 4 * h;
+          if (a >= p.NA) continue;  // NA is a multiple of 4: whole quad in or out
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+          if (EPI != EPI_DGELU && EPI != EPI_ACCUM && p.bias != nullptr) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + a);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bv[e];
+          }
+          const size_t o = (size_t)b * p.ldc + a;
+          if (EPI == EPI_BF16) {
+            u32x2 w = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + o) = w;
+          } else if (EPI == EPI_F32) {
+            f32x4 w = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + o) = w;
+          } else if (EPI == EPI_GELU) {
+            u32x2 w = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + o) = w;
+            // activation of the bf16-ROUNDED pre-activation, so backward (which only has the
+            // rounded value) differentiates exactly the function the forward evaluated
+            float y[4];
+            y[0] = gelu_f(bflo(w[0])); y[1] = gelu_f(bfhi(w[0]));
+            y[2] = gelu_f(bflo(w[1])); y[3] = gelu_f(bfhi(w[1]));
+            u32x2 w2 = {pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
+            *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C2) + o) = w2;
+          } else if (EPI == EPI_RESID) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.aux) + (size_t)b * p.ldaux + a);
+            f32x4 w = {v[0] + rv[0], v[1] + rv[1], v[2] + rv[2], v[3] + rv[3]};
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + o) = w;
+          } else if (EPI == EPI_DGELU) {
+            const u32x2 pre = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.aux) + (size_t)b * p.ldaux + a);
+            v[0] *= dgelu_f(bflo(pre[0])); v[1] *= dgelu_f(bfhi(pre[0]));
+            v[2] *= dgelu_f(bflo(pre[1])); v[3] *= dgelu_f(bfhi(pre[1]));
+            u32x2 w = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + o) = w;
+          }
+        }
+      }
+    }
+  } else {
+    // C[a][b] += X[a][b]: register g of acc[i][j] is row a = ... + (g&3) + 8*(g>>2) + 4h, the 32 lanes of a
+    // half-wave are 32 consecutive b: one register = two 128-B row segments (the full-rate atomic shape).
+    float* C = reinterpret_cast<float*>(p.C);
+    const bool atomic = gridDim.z > 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int b = b0 + wb * 64 + j * 32 + r;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int a = a0 + wa * 64 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+          if (a < p.NA && b < p.NB) {
+            float* dst = C + (size_t)a * p.ldc + b;
+            if (atomic) unsafeAtomicAdd(dst, acc[i][j][g]);
+            else *dst += acc[i][j][g];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <bool A_KS, bool B_KS, int EPI, bool OUT_AB>
+static int launch(const GemmParams& p, int splitk, hipStream_t st) {
+  auto kern = gemm_kernel<A_KS, B_KS, EPI, OUT_AB>;
+  static bool attr_set = false;  // benign race: idempotent
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_a * p.tiles_b, 1, splitk);
+  hipLaunchKernelGGL(kern, grid, dim3(256), 4 * TILE_BYTES, st, p);
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace octmae
+
+using namespace octmae;
+
+// C[b][a] (+epilogue) = sum_k A[a][k] B[b][k];  see include/octmae.h for the contract.
+extern "C" int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
+                                int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided,
+                                int b_kstrided, int epilogue, int splitk, void* stream) {
+  OCTMAE_CHECK_ARG(A && B && C);
+  OCTMAE_CHECK_ARG(NA > 0 && NB > 0 && K > 0);
+  OCTMAE_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0);
+  OCTMAE_CHECK_ARG(epilogue >= 0 && epilogue <= 5);
+  // contiguous-dimension granularity: 16-byte chunks of 8 bf16
+  if (!a_kstrided) OCTMAE_CHECK_ARG(K % 8 == 0); else OCTMAE_CHECK_ARG(NA % 8 == 0);
+  if (!b_kstrided) OCTMAE_CHECK_ARG(K % 8 == 0); else OCTMAE_CHECK_ARG(NB % 8 == 0);
+  if (epilogue != EPI_ACCUM) OCTMAE_CHECK_ARG(NA % 4 == 0 && ldc % 4 == 0);
+  if (epilogue == EPI_GELU) OCTMAE_CHECK_ARG(C2 != nullptr);
+  if (epilogue == EPI_RESID || epilogue == EPI_DGELU) OCTMAE_CHECK_ARG(aux != nullptr && ldaux % 4 == 0);
+  if (splitk < 1) splitk = 1;
+  if (epilogue != EPI_ACCUM) splitk = 1;
+
+  GemmParams p;
+  p.A = reinterpret_cast<const bf16_t*>(A);
+  p.B = reinterpret_cast<const bf16_t*>(B);
+  p.C = C; p.C2 = C2; p.bias = bias; p.aux = aux;
+  p.NA = NA; p.NB = NB; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
+  p.tiles_a = (NA + TA - 1) / TA;
+  p.tiles_b = (NB + TB - 1) / TB;
+  p.ktiles = (K + TK - 1) / TK;
+  if (splitk > p.ktiles) splitk = p.ktiles;
+  p.ktiles_per_split = (p.ktiles + splitk - 1) / splitk;
+  splitk = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+#define OCTMAE_GEMM_CASE(AKS, BKS, E, AB) \
+  if (a_kstrided == AKS && b_kstrided == BKS && epilogue == E) return launch<AKS, BKS, E, AB>(p, splitk, st);
+  // forward linears (nn.Linear layout both sides)
+  OCTMAE_GEMM_CASE(0, 0, EPI_BF16, false)
+  OCTMAE_GEMM_CASE(0, 0, EPI_F32, false)
+  OCTMAE_GEMM_CASE(0, 0, EPI_GELU, false)
+  OCTMAE_GEMM_CASE(0, 0, EPI_RESID, false)
+  // dgrad (weight read k-strided)
+  OCTMAE_GEMM_CASE(1, 0, EPI_BF16, false)
+  OCTMAE_GEMM_CASE(1, 0, EPI_F32, false)
+  OCTMAE_GEMM_CASE(1, 0, EPI_DGELU, false)
+  // wgrad (both k-strided, fp32 accumulate, lane-contiguous output)
+  OCTMAE_GEMM_CASE(1, 1, EPI_ACCUM, true)
+  OCTMAE_GEMM_CASE(1, 1, EPI_F32, false)
+  OCTMAE_GEMM_CASE(0, 0, EPI_ACCUM, true)
+#undef OCTMAE_GEMM_CASE
+  return -2;  // layout / epilogue combination not built
+}

@@ -1,0 +1,226 @@
+// LayerNorm forward / backward over the fp32 residual stream (reference K5: nn.LayerNorm eps=1e-6,
+// Pre-training/models_mae_joint_res_flash_attn.py:799; applied at video_vit.py:181-184, :489, :592).
+//
+// HBM-bound: one wave owns one token row, lane t holds float4 chunks t, t+64, ... (16-byte coalesced
+// loads), statistics by wave64 butterfly shuffles, bf16 output packed 8 bytes per chunk.
+//   fwd bytes/element: 4 (x) read + 2 (y) write
+//   bwd bytes/element: 2 (dy) + 4 (x) read, 4 (dx) [+2 (dx bf16)] write; dgamma/dbeta/column sums are
+//   accumulated per lane across the rows a wave walks, reduced over the block in LDS and added with
+//   one fp32 atomic per column per block.
+#include "common.hpp"
+#include "../../include/octmae.h"
+
+namespace octmae {
+
+constexpr int LN_MAXC = 8;  // float4 chunks per lane -> D <= 2048
+
+template <int NC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M, int D,
+                                                     float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  const int nchunk = D >> 2;
+  const float invD = 1.0f / (float)D;
+  f32x4 g[NC], b[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int ci = lane + 64 * c;
+    if (ci < nchunk) {
+      g[c] = *reinterpret_cast<const f32x4*>(gamma + 4 * ci);
+      b[c] = *reinterpret_cast<const f32x4*>(beta + 4 * ci);
+    }
+  }
+  for (int row = wave; row < M; row += nwaves) {
+    const float* xr = x + (size_t)row * D;
+    f32x4 v[NC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int ci = lane + 64 * c;
+      if (ci < nchunk) {
+        v[c] = *reinterpret_cast<const f32x4*>(xr + 4 * ci);
+        s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+      }
+    }
+    const float mu = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int ci = lane + 64 * c;
+      if (ci < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = v[c][e] - mu;
+          q = fmaf(d, d, q);
+        }
+      }
+    }
+    const float var = wave_sum(q) * invD;
+    const float rs = rsqrtf(var + eps);
+    if (lane == 0) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
+    bf16_t* yr = y + (size_t)row * D;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int ci = lane + 64 * c;
+      if (ci < nchunk) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaf((v[c][e] - mu) * rs, g[c][e], b[c][e]);
+        u32x2 w = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        *reinterpret_cast<u32x2*>(yr + 4 * ci) = w;
+      }
+    }
+  }
+}
+
+// dx = [dres +] rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * gamma
+template <int NC>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                     float* __restrict__ dx, bf16_t* __restrict__ dxb,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ dxsum, int M, int D) {
+  __shared__ float red[3][4][64 * 4 + 4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wave = blockIdx.x * 4 + w;
+  const int nwaves = gridDim.x * 4;
+  const int nchunk = D >> 2;
+  const float invD = 1.0f / (float)D;
+  f32x4 g[NC], ag[NC], ab[NC], as[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int ci = lane + 64 * c;
+    if (ci < nchunk) g[c] = *reinterpret_cast<const f32x4*>(gamma + 4 * ci);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; as[c][e] = 0.f; }
+  }
+  for (int row = wave; row < M; row += nwaves) {
+    const float mu = mean[row], rs = rstd[row];
+    const float* xr = x + (size_t)row * D;
+    const bf16_t* dyr = dy + (size_t)row * D;
+    f32x4 xh[NC], gy[NC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int ci = lane + 64 * c;
+      if (ci < nchunk) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + 4 * ci);
+        const u32x2 dw = *reinterpret_cast<const u32x2*>(dyr + 4 * ci);
+        const float d[4] = {bflo(dw[0]), bfhi(dw[0]), bflo(dw[1]), bfhi(dw[1])};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[c][e] = (xv[e] - mu) * rs;
+          gy[c][e] = d[e] * g[c][e];
+          s1 += gy[c][e];
+          s2 = fmaf(gy[c][e], xh[c][e], s2);
+          ag[c][e] = fmaf(d[e], xh[c][e], ag[c][e]);
+          ab[c][e] += d[e];
+        }
+      }
+    }
+    const float m1 = wave_sum(s1) * invD, m2 = wave_sum(s2) * invD;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int ci = lane + 64 * c;
+      if (ci < nchunk) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (gy[c][e] - m1 - xh[c][e] * m2);
+        if (dres != nullptr) {
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(dres + (size_t)row * D + 4 * ci);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] += rv[e];
+        }
+        *reinterpret_cast<f32x4*>(dx + (size_t)row * D + 4 * ci) = o;
+        if (dxb != nullptr) {
+          u32x2 wv = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+          *reinterpret_cast<u32x2*>(dxb + (size_t)row * D + 4 * ci) = wv;
+        }
+        if (dxsum != nullptr) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) as[c][e] += o[e];
+        }
+      }
+    }
+  }
+  // block reduction of the per-lane column partials, one chunk slot at a time
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int ci = lane + 64 * c;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[0][w][lane * 4 + e] = ag[c][e];
+      red[1][w][lane * 4 + e] = ab[c][e];
+      red[2][w][lane * 4 + e] = as[c][e];
+    }
+    __syncthreads();
+    if (w < 3 && ci < nchunk) {
+      float* dst = (w == 0) ? dgamma : (w == 1) ? dbeta : dxsum;
+      if (dst != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = (red[w][0][lane * 4 + e] + red[w][1][lane * 4 + e]) + (red[w][2][lane * 4 + e] + red[w][3][lane * 4 + e]);
+          unsafeAtomicAdd(dst + 4 * ci + e, t);
+        }
+      }
+    }
+  }
+}
+
+static inline int ln_grid(int M) {
+  int blocks = (M + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  return blocks;
+}
+
+}  // namespace octmae
+using namespace octmae;
+
+extern "C" int octmae_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean,
+                                    float* rstd, int M, int D, float eps, void* stream) {
+  OCTMAE_CHECK_ARG(x && gamma && beta && y_bf16 && mean && rstd);
+  OCTMAE_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXC);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nc = (D / 4 + 63) / 64;
+  bf16_t* y = reinterpret_cast<bf16_t*>(y_bf16);
+  dim3 grid(ln_grid(M)), blk(256);
+  switch (nc) {
+    case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, blk, 0, st, x, gamma, beta, y, mean, rstd, M, D, eps); break;
+    case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, blk, 0, st, x, gamma, beta, y, mean, rstd, M, D, eps); break;
+    case 3: case 4: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, blk, 0, st, x, gamma, beta, y, mean, rstd, M, D, eps); break;
+    default: hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, blk, 0, st, x, gamma, beta, y, mean, rstd, M, D, eps); break;
+  }
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int octmae_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
+                                    const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgamma,
+                                    float* dbeta, float* dxsum, int M, int D, void* stream) {
+  OCTMAE_CHECK_ARG(dy_bf16 && x && mean && rstd && gamma && dx);
+  OCTMAE_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXC);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nc = (D / 4 + 63) / 64;
+  const bf16_t* dy = reinterpret_cast<const bf16_t*>(dy_bf16);
+  bf16_t* dxb = reinterpret_cast<bf16_t*>(dx_bf16);
+  int blocks = ln_grid(M);
+  if (blocks > 1024) blocks = 1024;
+  dim3 grid(blocks), blk(256);
+  switch (nc) {
+    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, blk, 0, st, dy, x, mean, rstd, gamma, dres, dx, dxb, dgamma, dbeta, dxsum, M, D); break;
+    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, blk, 0, st, dy, x, mean, rstd, gamma, dres, dx, dxb, dgamma, dbeta, dxsum, M, D); break;
+    case 3: case 4: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, blk, 0, st, dy, x, mean, rstd, gamma, dres, dx, dxb, dgamma, dbeta, dxsum, M, D); break;
+    default: hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, blk, 0, st, dy, x, mean, rstd, gamma, dres, dx, dxb, dgamma, dbeta, dxsum, M, D); break;
+  }
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,391 @@
+// HBM-bound token plumbing of the 3-D MAE path (reference K1 gather side, K3, K9, K10):
+//   cast / column sums, patch gather (im2col of kept tokens only), encoder / decoder sequence assembly,
+//   fused patchify + masked-MSE forward and backward.
+// All kernels move 16 bytes per lane per access along the contiguous axis.
+#include "common.hpp"
+#include "../../include/octmae.h"
+
+namespace octmae {
+
+// ---------------------------------------------------------------------------------------------
+// fp32 -> bf16 cast (weight arena refresh, gradient cast).  8 elements per thread.
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+  const size_t n8 = n >> 3;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + 8 * i);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(src + 8 * i + 4);
+    u32x4 w = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+    *reinterpret_cast<u32x4*>(dst + 8 * i) = w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const size_t i = (n8 << 3) + threadIdx.x;
+    dst[i] = f2bf(src[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[c] += sum_rows in[r][c]   (bias gradients).  Block = 32 row-lanes x 8 column-lanes of 8 columns.
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ in, float* __restrict__ out, int M, int N,
+                                                     int ld, int rows_per_block) {
+  __shared__ float red[32][65];
+  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * 64 + cl * 8;
+  const int r0 = blockIdx.y * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (c0 < N) {
+    for (int r = r0 + rl; r < r1; r += 32) {
+      if (IN_BF16) {
+        const u32x4 w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(in) + (size_t)r * ld + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[2 * e] += bflo(w[e]); acc[2 * e + 1] += bfhi(w[e]); }
+      } else {
+        const float* p = reinterpret_cast<const float*>(in) + (size_t)r * ld + c0;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[e] += a[e]; acc[4 + e] += b[e]; }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][cl * 8 + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) s += red[r][threadIdx.x];
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < N) unsafeAtomicAdd(out + c, s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Patch gather = im2col restricted to the kept tokens (the reference embeds all L tokens and gathers
+// afterwards, video_vit.py:80-82 then models_mae…:363; embedding only the kept rows is output-identical).
+// out[row = b*nkeep + i][ (c, u, py, px) ] = imgs[b][c][t*tp + u][hy*p + py][wx*p + px],  token id -> (t, hy, wx).
+// One thread = 8 consecutive px (32 B fp32 read -> 16 B bf16 write).
+template <typename IdxT>
+__global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restrict__ imgs, const IdxT* __restrict__ ids,
+                                                           bf16_t* __restrict__ out, int B, int C, int T, int H, int W,
+                                                           int tp, int p, int nkeep, int L) {
+  const int gh = H / p, gw = W / p;
+  const int pc = p >> 3;                   // 8-px chunks per patch row
+  const int kdim = C * tp * p * p;
+  const int chunks_per_tok = kdim >> 3;
+  const size_t total = (size_t)B * nkeep * chunks_per_tok;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+    const int ch = (int)(q % chunks_per_tok);
+    const size_t row = q / chunks_per_tok;
+    const int b = (int)(row / nkeep), i = (int)(row % nkeep);
+    const int id = ids ? (int)ids[(size_t)b * nkeep + i] : i;
+    const int t = id / (gh * gw), hy = (id / gw) % gh, wx = id % gw;
+    const int px8 = ch % pc;
+    int rest = ch / pc;
+    const int py = rest % p; rest /= p;
+    const int u = rest % tp;
+    const int c = rest / tp;
+    const float* src = imgs + ((((size_t)b * C + c) * T + (t * tp + u)) * H + (hy * p + py)) * W + wx * p + px8 * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(src + 4);
+    u32x4 w = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(d[0], d[1]), pack2bf(d[2], d[3])};
+    *reinterpret_cast<u32x4*>(out + row * kdim + (size_t)ch * 8) = w;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Encoder sequence assembly (models_mae…:409-478): x[b][0] = cls + pos_cls; x[b][1+i] = tok[b][i] + pos[ids_keep[b][i]].
+template <typename IdxT>
+__global__ __launch_bounds__(256) void enc_assemble_kernel(const bf16_t* __restrict__ tok, const float* __restrict__ pos,
+                                                           const float* __restrict__ cls, const float* __restrict__ pos_cls,
+                                                           const IdxT* __restrict__ ids_keep, float* __restrict__ x, int B,
+                                                           int nkeep, int D) {
+  const int d4 = D >> 2;
+  const size_t total = (size_t)B * (nkeep + 1) * d4;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+    const int c = (int)(q % d4);
+    const size_t row = q / d4;
+    const int b = (int)(row / (nkeep + 1)), i = (int)(row % (nkeep + 1));
+    f32x4 o;
+    if (i == 0) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(cls + 4 * c);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(pos_cls + 4 * c);
+      o = a + d;
+    } else {
+      const int id = (int)ids_keep[(size_t)b * nkeep + i - 1];
+      const u32x2 w = *reinterpret_cast<const u32x2*>(tok + ((size_t)b * nkeep + i - 1) * D + 4 * c);
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(pos + (size_t)id * D + 4 * c);
+      o[0] = bflo(w[0]) + pv[0]; o[1] = bfhi(w[0]) + pv[1]; o[2] = bflo(w[1]) + pv[2]; o[3] = bfhi(w[1]) + pv[3];
+    }
+    *reinterpret_cast<f32x4*>(x + row * D + 4 * c) = o;
+  }
+}
+
+// Decoder sequence assembly (models_mae…:511-573): x[b][0] = dcls + dpos_cls;
+// x[b][1+j] = (ids_restore[b][j] < nkeep ? emb[b][ids_restore[b][j]] : mask_token) + dpos[j].
+template <typename IdxT>
+__global__ __launch_bounds__(256) void dec_assemble_kernel(const bf16_t* __restrict__ emb, const float* __restrict__ mask_token,
+                                                           const float* __restrict__ dpos, const float* __restrict__ dcls,
+                                                           const float* __restrict__ dpos_cls, const IdxT* __restrict__ ids_restore,
+                                                           float* __restrict__ x, int B, int nkeep, int L, int D) {
+  const int d4 = D >> 2;
+  const size_t total = (size_t)B * (L + 1) * d4;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+    const int c = (int)(q % d4);
+    const size_t row = q / d4;
+    const int b = (int)(row / (L + 1)), j = (int)(row % (L + 1));
+    f32x4 o;
+    if (j == 0) {
+      o = *reinterpret_cast<const f32x4*>(dcls + 4 * c) + *reinterpret_cast<const f32x4*>(dpos_cls + 4 * c);
+    } else {
+      const int r = (int)ids_restore[(size_t)b * L + j - 1];
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(dpos + (size_t)(j - 1) * D + 4 * c);
+      if (r < nkeep) {
+        const u32x2 w = *reinterpret_cast<const u32x2*>(emb + ((size_t)b * nkeep + r) * D + 4 * c);
+        o[0] = bflo(w[0]) + pv[0]; o[1] = bfhi(w[0]) + pv[1]; o[2] = bflo(w[1]) + pv[2]; o[3] = bfhi(w[1]) + pv[3];
+      } else {
+        o = *reinterpret_cast<const f32x4*>(mask_token + 4 * c) + pv;
+      }
+    }
+    *reinterpret_cast<f32x4*>(x + row * D + 4 * c) = o;
+  }
+}
+
+// Row gather with fp32 -> bf16 cast: out[b*n + i][:] = src[b][1 + ids[b][i]][:]  (src rows include the cls slot).
+// Backward of both assemblies w.r.t. the token matrix: ids = ids_keep (a permutation prefix), so a pure gather.
+// ids == nullptr means identity (out[b*n+i] = src[b][1+i]).
+template <typename IdxT>
+__global__ __launch_bounds__(256) void gather_rows_cast_kernel(const float* __restrict__ src, const IdxT* __restrict__ ids,
+                                                               bf16_t* __restrict__ out, int B, int n, int src_rows, int D) {
+  const int d8 = D >> 3;
+  const size_t total = (size_t)B * n * d8;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+    const int c = (int)(q % d8);
+    const size_t row = q / d8;
+    const int b = (int)(row / n), i = (int)(row % n);
+    const int id = ids ? (int)ids[(size_t)b * n + i] : i;
+    const float* s = src + ((size_t)b * src_rows + 1 + id) * D + 8 * c;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(s);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(s + 4);
+    u32x4 w = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(d[0], d[1]), pack2bf(d[2], d[3])};
+    *reinterpret_cast<u32x4*>(out + row * D + 8 * c) = w;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused patchify + masked MSE (models_mae…:289-314, :613-667).  One wave per token.
+// target[(u, py, px, c)] = imgs[b][c][fi(t*u_sz + u)][hy*p + py][wx*p + px]; fi = linspace frame select (identity
+// when pred_t_dim == T).  pred rows live in a [B][L+1][PD] buffer (row 0 of each sample = cls, skipped).
+// MODE 0: loss_tok[b][l] = mean_e (pred - target)^2           (forward)
+// MODE 1: dpred[b][1+l][e] = coef * mask[b][l] * (pred - target), dpred[b][0][:] = 0, bf16 (backward)
+template <int MODE>
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, const float* __restrict__ imgs,
+                                                  const int* __restrict__ frame_idx, const float* __restrict__ mask,
+                                                  const float* __restrict__ coef_ptr, float* __restrict__ loss_tok,
+                                                  bf16_t* __restrict__ dpred, int B, int C, int T, int H, int W, int u_sz,
+                                                  int p, int L, int norm_pix) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  const int gh = H / p, gw = W / p;
+  const int PD = u_sz * p * p * C;
+  const int nq = PD >> 2;  // float4 groups along (u,py,px,c); contiguous in pred
+  const float coef = (MODE == 1) ? *coef_ptr : 0.f;
+  const int rows = (MODE == 1) ? B * (L + 1) : B * L;
+  for (int row = wave; row < rows; row += nwaves) {
+    int b, l;
+    if (MODE == 1) {
+      b = row / (L + 1);
+      l = row % (L + 1) - 1;
+      if (l < 0) {
+        for (int q = lane; q < (PD >> 3); q += 64) {
+          u32x4 z = {0u, 0u, 0u, 0u};
+          *reinterpret_cast<u32x4*>(dpred + (size_t)row * PD + 8 * q) = z;
+        }
+        continue;
+      }
+    } else {
+      b = row / L;
+      l = row % L;
+    }
+    const float mk = (MODE == 1) ? mask[(size_t)b * L + l] : 0.f;
+    const int t = l / (gh * gw), hy = (l / gw) % gh, wx = l % gw;
+    const float* pr = pred + ((size_t)b * (L + 1) + 1 + l) * PD;
+    // target statistics for norm_pix_loss (unbiased variance, torch.var default)
+    float mu = 0.f, inv = 1.f;
+    if (norm_pix) {
+      float s = 0.f, s2 = 0.f;
+      for (int e = lane; e < PD; e += 64) {
+        const int c = e % C; int rest = e / C;
+        const int px = rest % p; rest /= p;
+        const int py = rest % p; const int u = rest / p;
+        const int f = frame_idx ? frame_idx[t * u_sz + u] : t * u_sz + u;
+        const float v = imgs[((((size_t)b * C + c) * T + f) * H + hy * p + py) * W + wx * p + px];
+        s += v;
+      }
+      mu = wave_sum(s) / (float)PD;
+      for (int e = lane; e < PD; e += 64) {
+        const int c = e % C; int rest = e / C;
+        const int px = rest % p; rest /= p;
+        const int py = rest % p; const int u = rest / p;
+        const int f = frame_idx ? frame_idx[t * u_sz + u] : t * u_sz + u;
+        const float v = imgs[((((size_t)b * C + c) * T + f) * H + hy * p + py) * W + wx * p + px] - mu;
+        s2 = fmaf(v, v, s2);
+      }
+      const float var = wave_sum(s2) / (float)(PD - 1);
+      inv = rsqrtf(var + 1.0e-6f);
+    }
+    float acc = 0.f;
+    for (int q = lane; q < nq; q += 64) {
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(pr + 4 * q);
+      float tg[4];
+      if (C == 1) {  // 4 consecutive px of one patch row: a 16-byte image read
+        const int e = 4 * q;
+        const int px = e % p; int rest = e / p;
+        const int py = rest % p; const int u = rest / p;
+        const int f = frame_idx ? frame_idx[t * u_sz + u] : t * u_sz + u;
+        const f32x4 iv = *reinterpret_cast<const f32x4*>(imgs + (((size_t)b * T + f) * H + hy * p + py) * W + wx * p + px);
+        tg[0] = iv[0]; tg[1] = iv[1]; tg[2] = iv[2]; tg[3] = iv[3];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = 4 * q + k;
+          const int c = e % C; int rest = e / C;
+          const int px = rest % p; rest /= p;
+          const int py = rest % p; const int u = rest / p;
+          const int f = frame_idx ? frame_idx[t * u_sz + u] : t * u_sz + u;
+          tg[k] = imgs[((((size_t)b * C + c) * T + f) * H + hy * p + py) * W + wx * p + px];
+        }
+      }
+      float d[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        d[k] = pv[k] - (tg[k] - mu) * inv;
+        acc = fmaf(d[k], d[k], acc);
+      }
+      if (MODE == 1) {
+        const float s = coef * mk;
+        u32x2 w = {pack2bf(s * d[0], s * d[1]), pack2bf(s * d[2], s * d[3])};
+        *reinterpret_cast<u32x2*>(dpred + (size_t)row * PD + 4 * q) = w;
+      }
+    }
+    if (MODE == 0) {
+      acc = wave_sum(acc);
+      if (lane == 0) loss_tok[(size_t)b * L + l] = acc / (float)PD;
+    }
+  }
+}
+
+static inline int grid_for(size_t work_items, int per_block = 256, int cap = 4096) {
+  size_t g = (work_items + per_block - 1) / per_block;
+  if (g > (size_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace octmae
+using namespace octmae;
+
+extern "C" int octmae_cast_f32_bf16(const float* src, void* dst_bf16, long long n, void* stream) {
+  OCTMAE_CHECK_ARG(src && dst_bf16 && n >= 0);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for((size_t)n / 8 + 1)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), src, reinterpret_cast<bf16_t*>(dst_bf16), (size_t)n);
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int octmae_colsum_accum(const void* in, int in_is_bf16, float* out, int M, int N, int ld, void* stream) {
+  OCTMAE_CHECK_ARG(in && out && M > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0);
+  int splits = (M + 255) / 256;
+  if (splits > 128) splits = 128;
+  int rpb = (M + splits - 1) / splits;
+  rpb = (rpb + 31) / 32 * 32;
+  splits = (M + rpb - 1) / rpb;
+  dim3 grid((N + 63) / 64, splits);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (in_is_bf16) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, st, in, out, M, N, ld, rpb);
+  else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, st, in, out, M, N, ld, rpb);
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int octmae_patch_gather(const float* imgs, const void* ids, int ids_is_i64, void* out_bf16, int B, int C, int T,
+                                   int H, int W, int tp, int p, int nkeep, void* stream) {
+  OCTMAE_CHECK_ARG(imgs && out_bf16 && B > 0 && C > 0 && nkeep > 0);
+  OCTMAE_CHECK_ARG(p % 8 == 0 && H % p == 0 && W % p == 0 && T % tp == 0 && W % 4 == 0);
+  const int L = (T / tp) * (H / p) * (W / p);
+  OCTMAE_CHECK_ARG(nkeep <= L);
+  const size_t total = (size_t)B * nkeep * (C * tp * p * p / 8);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  bf16_t* out = reinterpret_cast<bf16_t*>(out_bf16);
+  if (ids_is_i64)
+    hipLaunchKernelGGL(patch_gather_kernel<long long>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, st, imgs,
+                       reinterpret_cast<const long long*>(ids), out, B, C, T, H, W, tp, p, nkeep, L);
+  else
+    hipLaunchKernelGGL(patch_gather_kernel<int>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, st, imgs,
+                       reinterpret_cast<const int*>(ids), out, B, C, T, H, W, tp, p, nkeep, L);
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int octmae_enc_assemble(const void* tok_bf16, const float* pos, const float* cls, const float* pos_cls,
+                                   const long long* ids_keep, float* x, int B, int nkeep, int D, void* stream) {
+  OCTMAE_CHECK_ARG(tok_bf16 && pos && cls && pos_cls && ids_keep && x && B > 0 && nkeep > 0 && D % 4 == 0);
+  const size_t total = (size_t)B * (nkeep + 1) * (D / 4);
+  hipLaunchKernelGGL(enc_assemble_kernel<long long>, dim3(grid_for(total, 256, 8192)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16_t*>(tok_bf16), pos, cls, pos_cls,
+                     ids_keep, x, B, nkeep, D);
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int octmae_dec_assemble(const void* emb_bf16, const float* mask_token, const float* dpos, const float* dcls,
+                                   const float* dpos_cls, const long long* ids_restore, float* x, int B, int nkeep, int L,
+                                   int D, void* stream) {
+  OCTMAE_CHECK_ARG(emb_bf16 && mask_token && dpos && dcls && dpos_cls && ids_restore && x);
+  OCTMAE_CHECK_ARG(B > 0 && nkeep > 0 && L >= nkeep && D % 4 == 0);
+  const size_t total = (size_t)B * (L + 1) * (D / 4);
+  hipLaunchKernelGGL(dec_assemble_kernel<long long>, dim3(grid_for(total, 256, 8192)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16_t*>(emb_bf16), mask_token, dpos,
+                     dcls, dpos_cls, ids_restore, x, B, nkeep, L, D);
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int octmae_gather_rows_cast(const float* src, const long long* ids, void* out_bf16, int B, int n, int src_rows,
+                                       int D, void* stream) {
+  OCTMAE_CHECK_ARG(src && out_bf16 && B > 0 && n > 0 && src_rows >= n + 1 && D % 8 == 0);
+  const size_t total = (size_t)B * n * (D / 8);
+  hipLaunchKernelGGL(gather_rows_cast_kernel<long long>, dim3(grid_for(total, 256, 8192)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), src, ids, reinterpret_cast<bf16_t*>(out_bf16), B, n, src_rows, D);
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int octmae_mse_fwd(const float* pred, const float* imgs, const int* frame_idx, float* loss_tok, int B, int C,
+                              int T, int H, int W, int u_sz, int p, int L, int norm_pix, void* stream) {
+  OCTMAE_CHECK_ARG(pred && imgs && loss_tok && B > 0 && L > 0);
+  OCTMAE_CHECK_ARG(p % 4 == 0 && (u_sz * p * p * C) % 8 == 0 && W % 4 == 0);
+  hipLaunchKernelGGL(mse_kernel<0>, dim3(grid_for((size_t)B * L, 4, 4096)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     pred, imgs, frame_idx, loss_tok /*mask unused: any valid pointer*/, nullptr, loss_tok, nullptr, B, C, T, H,
+                     W, u_sz, p, L, norm_pix);
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int octmae_mse_bwd(const float* pred, const float* imgs, const int* frame_idx, const float* mask,
+                              const float* coef, void* dpred_bf16, int B, int C, int T, int H, int W, int u_sz, int p, int L,
+                              int norm_pix, void* stream) {
+  OCTMAE_CHECK_ARG(pred && imgs && mask && coef && dpred_bf16 && B > 0 && L > 0);
+  OCTMAE_CHECK_ARG(p % 4 == 0 && (u_sz * p * p * C) % 8 == 0 && W % 4 == 0);
+  hipLaunchKernelGGL(mse_kernel<1>, dim3(grid_for((size_t)B * (L + 1), 4, 4096)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), pred, imgs, frame_idx, mask, coef, nullptr,
+                     reinterpret_cast<bf16_t*>(dpred_bf16), B, C, T, H, W, u_sz, p, L, norm_pix);
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,260 @@
+"""Train-step utilities with the reference's call contracts (Pre-training/custom_util/misc.py):
+NativeScalerWithGradNormCount (:308-353), get_grad_norm_ (:356-373), add_weight_decay (:678-696),
+init_distributed_mode (:252-297), all_reduce_mean (:622-630), SmoothedValue / MetricLogger (:42-201).
+"""
+from __future__ import annotations
+
+import datetime
+import os
+import time
+from collections import defaultdict, deque
+
+import torch
+import torch.distributed as dist
+
+from . import optim as _optim
+
+
+# ------------------------------------------------------------------------------------------------
+# distributed helpers
+# ------------------------------------------------------------------------------------------------
+def is_dist_avail_and_initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size():
+    return dist.get_world_size() if is_dist_avail_and_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if is_dist_avail_and_initialized() else 0
+
+
+def is_main_process():
+    return get_rank() == 0
+
+
+def init_distributed_mode(args):
+    """One process per GPU.  Rank discovery from the torchrun / OpenMPI / SLURM environment exactly like the
+    reference; the backend is "nccl", which on ROCm IS RCCL (collectives over xGMI inside a node)."""
+    if getattr(args, "no_env", False):
+        pass
+    elif getattr(args, "dist_on_itp", False):
+        args.rank = int(os.environ["OMPI_COMM_WORLD_RANK"])
+        args.world_size = int(os.environ["OMPI_COMM_WORLD_SIZE"])
+        args.gpu = int(os.environ["OMPI_COMM_WORLD_LOCAL_RANK"])
+        args.dist_url = "tcp://%s:%s" % (os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"])
+        os.environ["LOCAL_RANK"] = str(args.gpu)
+        os.environ["RANK"] = str(args.rank)
+        os.environ["WORLD_SIZE"] = str(args.world_size)
+    elif "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        args.rank = int(os.environ["RANK"])
+        args.world_size = int(os.environ["WORLD_SIZE"])
+        args.gpu = int(os.environ["LOCAL_RANK"])
+    elif "SLURM_PROCID" in os.environ:
+        args.rank = int(os.environ["SLURM_PROCID"])
+        args.gpu = args.rank % max(torch.cuda.device_count(), 1)
+    else:
+        print("Not using distributed mode")
+        args.distributed = False
+        return
+    args.distributed = True
+    backend = getattr(args, "dist_backend", None) or ("nccl" if torch.cuda.is_available() else "gloo")
+    if backend == "nccl":
+        torch.cuda.set_device(args.gpu)
+    args.dist_backend = backend
+    if not hasattr(args, "dist_url") or args.dist_url is None:
+        args.dist_url = "env://"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    print(f"| distributed init (rank {args.rank}): {args.dist_url}, gpu {args.gpu}", flush=True)
+    dist.init_process_group(backend=backend, init_method=args.dist_url, world_size=args.world_size, rank=args.rank,
+                            timeout=datetime.timedelta(seconds=1800))
+    dist.barrier()
+
+
+def all_reduce_mean(x):
+    world_size = get_world_size()
+    if world_size > 1:
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        x_reduce = torch.tensor(x, dtype=torch.float32, device=dev)
+        dist.all_reduce(x_reduce)
+        x_reduce /= world_size
+        return x_reduce.item()
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# optimizer-side helpers
+# ------------------------------------------------------------------------------------------------
+def add_weight_decay(model, weight_decay=1e-5, skip_list=(), bias_wd=False):
+    """No weight decay for 1-D parameters / biases / names in skip_list (same grouping rule and group order
+    [no_decay, decay] as the reference)."""
+    decay, no_decay = [], []
+    for name, param in model.named_parameters():
+        if not param.requires_grad:
+            continue
+        if (not bias_wd) and len(param.shape) == 1 or name.endswith(".bias") or name in skip_list:
+            no_decay.append(param)
+        else:
+            decay.append(param)
+    return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
+
+
+_norm_cache: dict = {}
+
+
+def get_grad_norm_(parameters, norm_type: float = 2.0) -> torch.Tensor:
+    """Global gradient 2-norm (== the reference's norm of the stack of per-tensor norms), one fused
+    multi-tensor reduction instead of ~400 torch.norm launches."""
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    parameters = [p for p in parameters if p.grad is not None]
+    if len(parameters) == 0:
+        return torch.tensor(0.0)
+    if float(norm_type) != 2.0:
+        raise NotImplementedError("only the 2-norm is on the hot path")
+    norm, _ = _optim.grad_norm_and_coef(parameters, None, _norm_cache)
+    return norm
+
+
+class NativeScalerWithGradNormCount:
+    """``loss_scaler(loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True) -> norm``.
+
+    bf16 needs no loss scaling, so ``fp32=True``/bf16 runs keep scale == 1; the fp16 GradScaler state machine of
+    the reference is preserved for checkpoint compatibility (state_dict key "amp_scaler").  Gradient clipping is
+    applied inside the fused AdamW kernel as a device-side coefficient (no host synchronisation).
+    A ``reducer`` (parallel.FlatGradReducer) -- if given -- is flushed before the norm is taken, which is where the
+    data-parallel all-reduce that overlapped with backward is waited for.
+    """
+    state_dict_key = "amp_scaler"
+
+    def __init__(self, fp32=False, reducer=None):
+        self.enabled = False          # bf16 / fp32 path: scale is identically 1
+        self._scale = 1.0
+        self._growth_tracker = 0
+        self.reducer = reducer
+
+    def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True,
+                 cancel_last_layer_grad=False, named_parameters=None, epoch_and_freeze_last_layer_gradient_epoch=None):
+        if self.reducer is not None:
+            self.reducer.begin_backward(sync=update_grad)
+        loss.backward(create_graph=create_graph)
+        if not update_grad:
+            return None
+        if self.reducer is not None:
+            self.reducer.finish()
+        params = list(parameters) if parameters is not None else [p for g in optimizer.param_groups for p in g["params"]]
+        if clip_grad is not None:
+            assert parameters is not None
+        norm, coef = _optim.grad_norm_and_coef(params, clip_grad, _norm_cache)
+        if isinstance(optimizer, _optim.FusedAdamW):
+            optimizer.set_grad_scale(coef if clip_grad is not None else None)
+        elif clip_grad is not None:
+            for p in params:
+                if p.grad is not None:
+                    p.grad.mul_(coef)
+        optimizer.step()
+        return norm
+
+    def state_dict(self):
+        return {"scale": self._scale, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000,
+                "_growth_tracker": self._growth_tracker}
+
+    def load_state_dict(self, state_dict):
+        self._scale = float(state_dict.get("scale", 1.0)) if self.enabled else 1.0
+        self._growth_tracker = int(state_dict.get("_growth_tracker", 0))
+
+
+# ------------------------------------------------------------------------------------------------
+# logging
+# ------------------------------------------------------------------------------------------------
+class SmoothedValue:
+    """Windowed median / average plus a global average of a scalar series."""
+
+    def __init__(self, window_size=20, fmt=None):
+        self.deque = deque(maxlen=window_size)
+        self.total = 0.0
+        self.count = 0
+        self.fmt = fmt or "{median:.4f} ({global_avg:.4f})"
+
+    def update(self, value, n=1):
+        self.deque.append(value)
+        self.count += n
+        self.total += value * n
+
+    def synchronize_between_processes(self):
+        if not is_dist_avail_and_initialized():
+            return
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([self.count, self.total], dtype=torch.float64, device=dev)
+        dist.barrier()
+        dist.all_reduce(t)
+        self.count, self.total = int(t[0].item()), t[1].item()
+
+    @property
+    def median(self):
+        return torch.tensor(list(self.deque)).median().item()
+
+    @property
+    def avg(self):
+        return torch.tensor(list(self.deque), dtype=torch.float32).mean().item()
+
+    @property
+    def global_avg(self):
+        return self.total / max(self.count, 1)
+
+    @property
+    def max(self):
+        return max(self.deque)
+
+    @property
+    def value(self):
+        return self.deque[-1]
+
+    def __str__(self):
+        return self.fmt.format(median=self.median, avg=self.avg, global_avg=self.global_avg, max=self.max, value=self.value)
+
+
+class MetricLogger:
+    def __init__(self, delimiter="\t"):
+        self.meters = defaultdict(SmoothedValue)
+        self.delimiter = delimiter
+
+    def update(self, **kwargs):
+        for k, v in kwargs.items():
+            if v is None:
+                continue
+            if isinstance(v, torch.Tensor):
+                v = v.item()
+            self.meters[k].update(v)
+
+    def add_meter(self, name, meter):
+        self.meters[name] = meter
+
+    def __getattr__(self, attr):
+        if attr in self.meters:
+            return self.meters[attr]
+        raise AttributeError(attr)
+
+    def __str__(self):
+        return self.delimiter.join(f"{n}: {m}" for n, m in self.meters.items())
+
+    def synchronize_between_processes(self):
+        for m in self.meters.values():
+            m.synchronize_between_processes()
+
+    def log_every(self, iterable, print_freq, header=""):
+        start = time.time()
+        end = time.time()
+        iter_time = SmoothedValue(fmt="{avg:.4f}")
+        n = len(iterable) if hasattr(iterable, "__len__") else -1
+        for i, obj in enumerate(iterable):
+            yield obj
+            iter_time.update(time.time() - end)
+            if is_main_process() and (i % print_freq == 0 or i == n - 1):
+                mem = torch.cuda.max_memory_allocated() / 2 ** 20 if torch.cuda.is_available() else 0.0
+                print(f"{header} [{i}/{n}] {self} time: {iter_time} max mem: {mem:.0f}", flush=True)
+            end = time.time()
+        if is_main_process():
+            print(f"{header} Total time: {datetime.timedelta(seconds=int(time.time() - start))}", flush=True)

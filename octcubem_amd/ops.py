@@ -1,0 +1,515 @@
+"""Operators of the 3-D MAE hot path: thin wrappers over the C ABI (liboctmae.so) and the
+torch.autograd.Function glue that strings them into forward/backward.
+
+Numerics policy: fp32 residual stream / LayerNorm statistics / softmax statistics /
+accumulators / master weights and weight gradients; bf16 GEMM and attention operands.
+
+Weight gradients are accumulated by the wgrad GEMM (fp32, split-K) DIRECTLY into ``param.grad`` (the
+model pre-binds ``param.grad`` to views of one flat gradient arena, see models_mae._ParamArena), so the
+Functions below return ``None`` for parameters and call ``notify_grad_ready`` instead -- that is the hook
+the data-parallel reducer uses to overlap the RCCL all-reduce with backward.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from ._lib import call
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+EPI_BF16, EPI_F32, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM = range(6)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+# grad-ready notification (used by parallel.FlatGradReducer)
+# ------------------------------------------------------------------------------------------------
+_grad_ready_cb: Optional[Callable[[Sequence[torch.nn.Parameter]], None]] = None
+
+
+def set_grad_ready_callback(cb):
+    global _grad_ready_cb
+    _grad_ready_cb = cb
+
+
+def notify_grad_ready(params):
+    if _grad_ready_cb is not None:
+        _grad_ready_cb([p for p in params if p is not None])
+
+
+def grad_buf(p: torch.nn.Parameter) -> torch.Tensor:
+    """The fp32 buffer weight gradients are accumulated into (``p.grad``; created zeroed if absent)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+# ------------------------------------------------------------------------------------------------
+# per-launch timing (bench.py): HIP events on the stream the kernels are launched on
+# ------------------------------------------------------------------------------------------------
+class KernelTimer:
+    """Brackets single-kernel launches with events; kind -> [(start, end, algorithmic_flops, algorithmic_bytes)]."""
+
+    def __init__(self):
+        self.records = {}
+
+    def launch(self, kind, flops, nbytes, fn):
+        s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.records.setdefault(kind, []).append((s, e, flops, nbytes))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
+            out[kind] = {"launches": len(recs), "total_ms": ms, "avg_us": 1e3 * ms / len(recs),
+                         "flops": sum(r[2] for r in recs), "bytes": sum(r[3] for r in recs)}
+        return out
+
+
+KTIMER: Optional[KernelTimer] = None
+
+
+def _launch(kind, flops, nbytes, fn):
+    if KTIMER is None:
+        fn()
+    else:
+        KTIMER.launch(kind, flops, nbytes, fn)
+
+
+# ------------------------------------------------------------------------------------------------
+# raw ops
+# ------------------------------------------------------------------------------------------------
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype == BF16:
+        return x.contiguous()
+    _chk(x, F32, "cast_bf16")
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    call("octmae_cast_f32_bf16", x.data_ptr(), out.data_ptr(), x.numel(), _stream())
+    return out
+
+
+def cast_bf16_into(src: torch.Tensor, dst: torch.Tensor):
+    call("octmae_cast_f32_bf16", src.data_ptr(), dst.data_ptr(), src.numel(), _stream())
+
+
+def colsum_accum(x2d: torch.Tensor, out: torch.Tensor):
+    """out[c] += sum_r x2d[r][c] (fp32 accumulate)."""
+    M, N = x2d.shape
+    call("octmae_colsum_accum", x2d.data_ptr(), 1 if x2d.dtype == BF16 else 0, out.data_ptr(), M, N, x2d.stride(0), _stream())
+
+
+_GEMM_KIND = {(0, 0): "gemm_fwd", (1, 0): "gemm_dgrad", (1, 1): "gemm_wgrad"}
+
+
+def _gemm(A, B, C, NA, NB, K, lda, ldb, ldc, a_ks, b_ks, epi, C2=None, bias=None, aux=None, ldaux=0, splitk=1):
+    args = (A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(C2), _p(bias), _p(aux), NA, NB, K, lda, ldb, ldc, ldaux, a_ks, b_ks, epi,
+            splitk, _stream())
+    if KTIMER is None:
+        call("octmae_gemm_bf16", *args)
+    else:
+        kind = f"{_GEMM_KIND.get((a_ks, b_ks), 'gemm')}_epi{epi}"
+        KTIMER.launch(kind, 2.0 * NA * NB * K, 2.0 * (NA * K + NB * K) + C.element_size() * NA * NB,
+                      lambda: call("octmae_gemm_bf16", *args))
+
+
+def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mode: str = "bf16",
+               res: Optional[torch.Tensor] = None):
+    """y = x @ w.T + bias.  x bf16 [M,K], w bf16 [N,K], bias f32 [N].
+    mode: 'bf16' | 'f32' | 'gelu' (returns (pre, act)) | 'resid' (f32: res + y)."""
+    M, K = x.shape
+    N = w.shape[0]
+    dev = x.device
+    if mode == "bf16":
+        out = torch.empty((M, N), dtype=BF16, device=dev)
+        _gemm(w, x, out, N, M, K, w.stride(0), x.stride(0), N, 0, 0, EPI_BF16, bias=bias)
+        return out
+    if mode == "f32":
+        out = torch.empty((M, N), dtype=F32, device=dev)
+        _gemm(w, x, out, N, M, K, w.stride(0), x.stride(0), N, 0, 0, EPI_F32, bias=bias)
+        return out
+    if mode == "gelu":
+        pre = torch.empty((M, N), dtype=BF16, device=dev)
+        act = torch.empty((M, N), dtype=BF16, device=dev)
+        _gemm(w, x, pre, N, M, K, w.stride(0), x.stride(0), N, 0, 0, EPI_GELU, C2=act, bias=bias)
+        return pre, act
+    if mode == "resid":
+        out = torch.empty((M, N), dtype=F32, device=dev)
+        _gemm(w, x, out, N, M, K, w.stride(0), x.stride(0), N, 0, 0, EPI_RESID, bias=bias, aux=res, ldaux=res.stride(0))
+        return out
+    raise ValueError(mode)
+
+
+def linear_dgrad(dy: torch.Tensor, w: torch.Tensor, pre: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx[M,K] = dy[M,N] @ w[N,K]  (optionally * gelu'(pre[M,K])), bf16."""
+    M, N = dy.shape
+    K = w.shape[1]
+    dx = torch.empty((M, K), dtype=BF16, device=dy.device)
+    if pre is None:
+        _gemm(w, dy, dx, K, M, N, w.stride(0), dy.stride(0), K, 1, 0, EPI_BF16)
+    else:
+        _gemm(w, dy, dx, K, M, N, w.stride(0), dy.stride(0), K, 1, 0, EPI_DGELU, aux=pre, ldaux=pre.stride(0))
+    return dx
+
+
+def _splitk_for(n_out_tiles: int, ktiles: int) -> int:
+    # fill >= 2 workgroups per CU (512 on MI355X) but keep >= 8 k-tiles (512 rows) per slice
+    s = max(1, (512 + n_out_tiles - 1) // n_out_tiles)
+    return max(1, min(s, ktiles // 8 if ktiles >= 8 else 1))
+
+
+def linear_wgrad_accum(dy: torch.Tensor, x: torch.Tensor, gw: torch.Tensor):
+    """gw[N,K] (f32) += dy[M,N].T @ x[M,K]."""
+    M, N = dy.shape
+    K = x.shape[1]
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    ktiles = (M + 63) // 64
+    _gemm(dy, x, gw, N, K, M, dy.stride(0), x.stride(0), gw.stride(0), 1, 1, EPI_ACCUM, splitk=_splitk_for(tiles, ktiles))
+
+
+def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float):
+    M, D = x.shape
+    y = torch.empty((M, D), dtype=BF16, device=x.device)
+    mean = torch.empty((M,), dtype=F32, device=x.device)
+    rstd = torch.empty((M,), dtype=F32, device=x.device)
+    call("octmae_layernorm_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+         M, D, float(eps), _stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None, want_bf16=False, dxsum=None):
+    M, D = x.shape
+    dx = torch.empty((M, D), dtype=F32, device=x.device)
+    dxb = torch.empty((M, D), dtype=BF16, device=x.device) if want_bf16 else None
+    call("octmae_layernorm_bwd", dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), _p(dres),
+         dx.data_ptr(), _p(dxb), _p(dgamma), _p(dbeta), _p(dxsum), M, D, _stream())
+    return dx, dxb
+
+
+def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, HD: int, scale: float):
+    o = torch.empty((B * N, H * HD), dtype=BF16, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=F32, device=qkv.device)
+    _launch(f"attn_fwd_hd{HD}", 4.0 * B * H * N * N * HD, 2.0 * 4 * B * N * H * HD,
+            lambda: call("octmae_attn_fwd", qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, HD, float(scale), _stream()))
+    return o, lse
+
+
+def attn_bwd(qkv, o, dout, lse, B, N, H, HD, scale):
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, N), dtype=F32, device=qkv.device)
+    st = _stream()
+    call("octmae_attn_bwd_delta", o.data_ptr(), dout.data_ptr(), delta.data_ptr(), B, N, H, HD, st)
+    # algorithmic backward = 5 matmuls (10 B H N^2 HD flop); dq executes 3 of them, dkv 4 (S and dP are recomputed twice)
+    unit = 2.0 * B * H * N * N * HD
+    _launch(f"attn_bwd_dq_hd{HD}", 2 * unit, 2.0 * 5 * B * N * H * HD,
+            lambda: call("octmae_attn_bwd_dq", qkv.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, N,
+                         H, HD, float(scale), st))
+    _launch(f"attn_bwd_dkv_hd{HD}", 3 * unit, 2.0 * 6 * B * N * H * HD,
+            lambda: call("octmae_attn_bwd_dkv", qkv.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, N,
+                         H, HD, float(scale), st))
+    return dqkv
+
+
+def random_masking_ids(noise: torch.Tensor, len_keep: int, want_shuffle: bool = False):
+    """Index part of random_masking (models_mae_joint_res_flash_attn.py:349-369): stable argsort on the GPU.
+    Returns mask f32 [B,L], ids_restore i64 [B,L], ids_keep i64 [B,len_keep] (, ids_shuffle)."""
+    _chk(noise, F32, "noise")
+    Bn, L = noise.shape
+    dev = noise.device
+    ids_restore = torch.empty((Bn, L), dtype=torch.int64, device=dev)
+    ids_keep = torch.empty((Bn, len_keep), dtype=torch.int64, device=dev)
+    ids_shuffle = torch.empty((Bn, L), dtype=torch.int64, device=dev) if want_shuffle else None
+    mask = torch.empty((Bn, L), dtype=F32, device=dev)
+    call("octmae_random_masking_ids", noise.data_ptr(), ids_restore.data_ptr(), ids_keep.data_ptr(), _p(ids_shuffle), mask.data_ptr(),
+         Bn, L, len_keep, _stream())
+    if want_shuffle:
+        return mask, ids_restore, ids_keep, ids_shuffle
+    return mask, ids_restore, ids_keep
+
+
+def patch_gather(imgs: torch.Tensor, ids_keep: Optional[torch.Tensor], tp: int, p: int, nkeep: int) -> torch.Tensor:
+    _chk(imgs, F32, "imgs")
+    Bn, Cc, T, Hh, Ww = imgs.shape
+    out = torch.empty((Bn * nkeep, Cc * tp * p * p), dtype=BF16, device=imgs.device)
+    call("octmae_patch_gather", imgs.data_ptr(), _p(ids_keep), 1, out.data_ptr(), Bn, Cc, T, Hh, Ww, tp, p, nkeep, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd Functions
+# ------------------------------------------------------------------------------------------------
+def _as2d_bf16(g: torch.Tensor, cols: int) -> torch.Tensor:
+    return cast_bf16(g.reshape(-1, cols).contiguous())
+
+
+class LayerNormFn(torch.autograd.Function):
+    """y(bf16) = LayerNorm(x f32) -- nn.LayerNorm(eps=1e-6) at video_vit.py:181-184 / models_mae…:489,:592."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        shp = x.shape
+        x2 = _chk(x.reshape(-1, shp[-1]), F32, "layernorm input")
+        y, mean, rstd = layernorm_fwd(x2, gamma, beta, eps)
+        ctx.save_for_backward(x2, mean, rstd, gamma, beta)
+        ctx.shp = shp
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd, gamma, beta = ctx.saved_tensors
+        D = x2.shape[1]
+        dyb = _as2d_bf16(dy, D)
+        dx, _ = layernorm_bwd(dyb, x2, mean, rstd, gamma, grad_buf(gamma), grad_buf(beta))
+        notify_grad_ready((gamma, beta))
+        return dx.view(ctx.shp), None, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b on bf16 operands.  ``w_lp`` / ``b32`` are the (possibly fused q|k|v) bf16 weight and fp32 bias
+    views; ``params`` = (weight params..., bias params...) whose .grad buffers are adjacent views of the arena."""
+
+    @staticmethod
+    def forward(ctx, x, w_lp, b32, gw, gb, out_f32, *params):
+        shp = x.shape
+        x2 = cast_bf16(x.reshape(-1, shp[-1]))
+        y = linear_fwd(x2, w_lp, b32, "f32" if out_f32 else "bf16")
+        ctx.save_for_backward(x2, w_lp)
+        ctx.gw, ctx.gb, ctx.params, ctx.shp = gw, gb, params, shp
+        return y.view(*shp[:-1], w_lp.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w_lp = ctx.saved_tensors
+        N = w_lp.shape[0]
+        dyb = _as2d_bf16(dy, N)
+        gw, gb = ctx.gw(), ctx.gb()
+        linear_wgrad_accum(dyb, x2, gw)
+        if gb is not None:
+            colsum_accum(dyb, gb)
+        notify_grad_ready(ctx.params)
+        dx = linear_dgrad(dyb, w_lp).view(ctx.shp) if ctx.needs_input_grad[0] else None
+        return (dx, None, None, None, None, None) + (None,) * len(ctx.params)
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """PatchEmbed (Conv3d k=s=(tp,p,p) as a GEMM, video_vit.py:74-83) restricted to the kept tokens."""
+
+    @staticmethod
+    def forward(ctx, imgs, ids_keep, w_lp, b32, gw, gb, tp, p, nkeep, weight, bias):
+        patches = patch_gather(imgs, ids_keep, tp, p, nkeep)
+        tok = linear_fwd(patches, w_lp, b32, "bf16")
+        ctx.save_for_backward(patches)
+        ctx.gw, ctx.gb, ctx.params = gw, gb, (weight, bias)
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        (patches,) = ctx.saved_tensors
+        dyb = _as2d_bf16(dtok, dtok.shape[-1])
+        gw = ctx.gw()
+        linear_wgrad_accum(dyb, patches, gw.view(gw.shape[0], -1))
+        colsum_accum(dyb, ctx.gb())
+        notify_grad_ready(ctx.params)
+        return (None,) * 11
+
+
+class AttentionFn(torch.autograd.Function):
+    """Attention (video_vit.py:112-138): fused q|k|v projection, flash attention core, output projection, and
+    (inside a Block, video_vit.py:182) the residual add fused into the projection epilogue."""
+
+    @staticmethod
+    def forward(ctx, y, res, wqkv_lp, bqkv32, wproj_lp, bproj32, grads, H, *params):
+        shp = y.shape
+        Bn, N, Cc = shp
+        HD = Cc // H
+        scale = HD ** -0.5
+        y2 = cast_bf16(y.reshape(-1, Cc))
+        qkv = linear_fwd(y2, wqkv_lp, bqkv32, "bf16")
+        o, lse = attn_fwd(qkv, Bn, N, H, HD, scale)
+        if res is not None:
+            out = linear_fwd(o, wproj_lp, bproj32, "resid", res=_chk(res.reshape(-1, Cc), F32, "residual"))
+        else:
+            out = linear_fwd(o, wproj_lp, bproj32, "bf16")
+        ctx.save_for_backward(y2, qkv, o, lse, wqkv_lp, wproj_lp)
+        ctx.meta = (Bn, N, H, HD, scale, res is not None)
+        ctx.grads, ctx.params, ctx.shp = grads, params, shp
+        return out.view(shp)
+
+    @staticmethod
+    def backward(ctx, dout):
+        y2, qkv, o, lse, wqkv_lp, wproj_lp = ctx.saved_tensors
+        Bn, N, H, HD, scale, has_res = ctx.meta
+        Cc = H * HD
+        gwqkv, gbqkv, gwproj, gbproj = ctx.grads()
+        d2 = dout.reshape(-1, Cc)
+        if not d2.is_contiguous():
+            d2 = d2.contiguous()
+        dob = cast_bf16(d2)
+        if gbproj is not None:
+            colsum_accum(d2 if d2.dtype in (F32, BF16) else dob, gbproj)
+        linear_wgrad_accum(dob, o, gwproj)
+        do = linear_dgrad(dob, wproj_lp)
+        dqkv = attn_bwd(qkv, o, do, lse, Bn, N, H, HD, scale)
+        if gbqkv is not None:
+            colsum_accum(dqkv, gbqkv)
+        linear_wgrad_accum(dqkv, y2, gwqkv)
+        notify_grad_ready(ctx.params)
+        dy = linear_dgrad(dqkv, wqkv_lp).view(ctx.shp)
+        dres = dout if has_res else None
+        return (dy, dres, None, None, None, None, None, None) + (None,) * len(ctx.params)
+
+
+class MlpFn(torch.autograd.Function):
+    """timm Mlp (fc1 -> exact GELU -> fc2) with the Block's residual add (video_vit.py:183) fused into fc2."""
+
+    @staticmethod
+    def forward(ctx, y, res, w1_lp, b1_32, w2_lp, b2_32, grads, *params):
+        shp = y.shape
+        Cc = shp[-1]
+        y2 = cast_bf16(y.reshape(-1, Cc))
+        pre, act = linear_fwd(y2, w1_lp, b1_32, "gelu")
+        if res is not None:
+            out = linear_fwd(act, w2_lp, b2_32, "resid", res=_chk(res.reshape(-1, Cc), F32, "residual"))
+        else:
+            out = linear_fwd(act, w2_lp, b2_32, "bf16")
+        ctx.save_for_backward(y2, pre, act, w1_lp, w2_lp)
+        ctx.grads, ctx.params, ctx.shp, ctx.has_res = grads, params, shp, res is not None
+        return out.view(shp)
+
+    @staticmethod
+    def backward(ctx, dout):
+        y2, pre, act, w1_lp, w2_lp = ctx.saved_tensors
+        Cc = ctx.shp[-1]
+        gw1, gb1, gw2, gb2 = ctx.grads()
+        d2 = dout.reshape(-1, Cc)
+        if not d2.is_contiguous():
+            d2 = d2.contiguous()
+        dob = cast_bf16(d2)
+        if gb2 is not None:
+            colsum_accum(d2, gb2)
+        linear_wgrad_accum(dob, act, gw2)
+        dpre = linear_dgrad(dob, w2_lp, pre=pre)
+        if gb1 is not None:
+            colsum_accum(dpre, gb1)
+        linear_wgrad_accum(dpre, y2, gw1)
+        notify_grad_ready(ctx.params)
+        dy = linear_dgrad(dpre, w1_lp).view(ctx.shp)
+        return (dy, dout if ctx.has_res else None, None, None, None, None, None) + (None,) * len(ctx.params)
+
+
+class EncAssembleFn(torch.autograd.Function):
+    """cls concat + gathered positional embedding (models_mae_joint_res_flash_attn.py:409-478)."""
+
+    @staticmethod
+    def forward(ctx, tok, pos, cls, pos_cls, ids_keep):
+        Bn, nkeep = ids_keep.shape
+        D = tok.shape[-1]
+        _chk(tok, BF16, "tokens")
+        pos2 = _chk(pos.reshape(-1, D), F32, "pos table")
+        x = torch.empty((Bn, nkeep + 1, D), dtype=F32, device=tok.device)
+        call("octmae_enc_assemble", tok.data_ptr(), pos2.data_ptr(), cls.data_ptr(), pos_cls.data_ptr(), ids_keep.data_ptr(),
+             x.data_ptr(), Bn, nkeep, D, _stream())
+        ctx.save_for_backward(ids_keep)
+        ctx.pos_shape, ctx.cls_shape, ctx.pc_shape = pos.shape, cls.shape, pos_cls.shape
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        (ids_keep,) = ctx.saved_tensors
+        dx = dx.contiguous()
+        Bn, n1, D = dx.shape
+        nkeep = n1 - 1
+        dtok = torch.empty((Bn * nkeep, D), dtype=BF16, device=dx.device)
+        call("octmae_gather_rows_cast", dx.data_ptr(), None, dtok.data_ptr(), Bn, nkeep, n1, D, _stream())
+        dpos = torch.zeros(ctx.pos_shape, dtype=F32, device=dx.device)
+        dpos.view(-1, D).index_add_(0, ids_keep.reshape(-1), dx[:, 1:, :].reshape(-1, D))
+        dc = dx[:, 0, :].sum(0)
+        return dtok, dpos, dc.view(ctx.cls_shape), dc.view(ctx.pc_shape).clone(), None
+
+
+class DecAssembleFn(torch.autograd.Function):
+    """mask-token append, un-shuffle, cls concat, positional embedding (models_mae_joint_res_flash_attn.py:515-573)."""
+
+    @staticmethod
+    def forward(ctx, emb, mask_token, dpos, dcls, dpos_cls, ids_restore, ids_keep):
+        Bn, L = ids_restore.shape
+        nkeep = ids_keep.shape[1]
+        D = emb.shape[-1]
+        _chk(emb, BF16, "decoder tokens")
+        dpos2 = _chk(dpos.reshape(-1, D), F32, "decoder pos table")
+        x = torch.empty((Bn, L + 1, D), dtype=F32, device=emb.device)
+        call("octmae_dec_assemble", emb.data_ptr(), mask_token.data_ptr(), dpos2.data_ptr(), dcls.data_ptr(), dpos_cls.data_ptr(),
+             ids_restore.data_ptr(), x.data_ptr(), Bn, nkeep, L, D, _stream())
+        ctx.save_for_backward(ids_restore, ids_keep)
+        ctx.shapes = (mask_token.shape, dpos.shape, dcls.shape, dpos_cls.shape)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        ids_restore, ids_keep = ctx.saved_tensors
+        dx = dx.contiguous()
+        Bn, L1, D = dx.shape
+        nkeep = ids_keep.shape[1]
+        demb = torch.empty((Bn * nkeep, D), dtype=BF16, device=dx.device)
+        call("octmae_gather_rows_cast", dx.data_ptr(), ids_keep.data_ptr(), demb.data_ptr(), Bn, nkeep, L1, D, _stream())
+        body = dx[:, 1:, :]
+        masked = (ids_restore >= nkeep).to(F32).unsqueeze(-1)
+        dmask = (body * masked).sum((0, 1))
+        ddpos = body.sum(0)
+        dc = dx[:, 0, :].sum(0)
+        ms, ps, cs, pcs = ctx.shapes
+        return demb, dmask.view(ms), ddpos.view(ps), dc.view(cs), dc.view(pcs).clone(), None, None
+
+
+class PatchMSEFn(torch.autograd.Function):
+    """Fused patchify + per-token MSE (models_mae_joint_res_flash_attn.py:289-314, :649-650).
+    pred_full f32 [B, L+1, PD] (row 0 = cls) -> loss_tok f32 [B, L]."""
+
+    @staticmethod
+    def forward(ctx, pred_full, imgs, frame_idx, u_sz, p, norm_pix):
+        Bn, L1, PD = pred_full.shape
+        L = L1 - 1
+        _, Cc, T, Hh, Ww = imgs.shape
+        _chk(pred_full, F32, "pred"); _chk(imgs, F32, "imgs")
+        loss_tok = torch.empty((Bn, L), dtype=F32, device=imgs.device)
+        call("octmae_mse_fwd", pred_full.data_ptr(), imgs.data_ptr(), _p(frame_idx), loss_tok.data_ptr(), Bn, Cc, T, Hh, Ww, u_sz, p, L,
+             int(norm_pix), _stream())
+        ctx.save_for_backward(pred_full, imgs, frame_idx if frame_idx is not None else torch.empty(0, device=imgs.device))
+        ctx.meta = (u_sz, p, int(norm_pix), frame_idx is not None)
+        return loss_tok
+
+    @staticmethod
+    def backward(ctx, dl):
+        pred_full, imgs, frame_idx = ctx.saved_tensors
+        u_sz, p, norm_pix, has_fi = ctx.meta
+        Bn, L1, PD = pred_full.shape
+        _, Cc, T, Hh, Ww = imgs.shape
+        dl = dl.contiguous().to(F32)
+        coef = torch.full((1,), 2.0 / PD, dtype=F32, device=imgs.device)
+        dpred = torch.empty((Bn, L1, PD), dtype=BF16, device=imgs.device)
+        call("octmae_mse_bwd", pred_full.data_ptr(), imgs.data_ptr(), frame_idx.data_ptr() if has_fi else None, dl.data_ptr(),
+             coef.data_ptr(), dpred.data_ptr(), Bn, Cc, T, Hh, Ww, u_sz, p, L1 - 1, norm_pix, _stream())
+        return dpred, None, None, None, None, None

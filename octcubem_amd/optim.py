@@ -1,0 +1,108 @@
+"""Fused multi-tensor AdamW + gradient-norm kernels behind the torch.optim.Optimizer interface.
+
+Replaces ``torch.optim._multi_tensor.AdamW(param_groups, lr, betas=(0.9, 0.95))`` as built by the reference
+driver (main_pretrain_oph_joint_2d512_flash_attn.py:441-455): same param_groups / lr / lr_scale contract, so
+``lr_sched.adjust_learning_rate`` and ``misc.add_weight_decay`` work unchanged.  One kernel launch per group
+(16 B read + 12 B written per parameter), gradient clip / unscale folded in as a device-side scale.
+"""
+from __future__ import annotations
+
+import struct
+from typing import List, Optional
+
+import torch
+
+from ._lib import call
+from .ops import _stream
+
+
+class _MultiTensorTable:
+    """Device-side tables for a list of (p, g, m, v) tensors: octmae_mt_* calling convention."""
+
+    def __init__(self, ps: List[torch.Tensor], gs, ms, vs):
+        from ._lib import load
+        chunk = load().octmae_mt_chunk_elems()
+        dev = ps[0].device
+        raw = bytearray()
+        ct, co = [], []
+        for i, (p, g, m, v) in enumerate(zip(ps, gs, ms, vs)):
+            n = p.numel()
+            raw += struct.pack("<QQQQq", p.data_ptr(), g.data_ptr() if g is not None else 0,
+                               m.data_ptr() if m is not None else 0, v.data_ptr() if v is not None else 0, n)
+            for off in range(0, n, chunk):
+                ct.append(i); co.append(off)
+        self.n_tensors = len(ps)
+        self.n_chunks = len(ct)
+        self.table = torch.frombuffer(raw, dtype=torch.uint8).clone().to(dev)
+        self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=dev)
+        self.chunk_off = torch.tensor(co, dtype=torch.int64, device=dev)
+        self.key = tuple((p.data_ptr(), g.data_ptr() if g is not None else 0) for p, g in zip(ps, gs))
+
+
+def grad_norm_and_coef(params, max_norm: Optional[float], cache: dict):
+    """get_grad_norm_ (misc.py:356-373) / clip_grad_norm_ statistics in two launches.
+    Returns (total_norm, clip_coef) as 0-dim device tensors; clip_coef == 1 when max_norm is None."""
+    ps = [p for p in params if p.grad is not None]
+    if not ps:
+        return torch.tensor(0.0), None
+    key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
+    tab = cache.get("norm")
+    if tab is None or tab.key != key:
+        tab = _MultiTensorTable([p.data for p in ps], [p.grad for p in ps], [None] * len(ps), [None] * len(ps))
+        cache["norm"] = tab
+    dev = ps[0].device
+    sumsq = torch.zeros(tab.n_tensors, dtype=torch.float32, device=dev)
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    call("octmae_mt_sumsq", tab.table.data_ptr(), tab.chunk_tensor.data_ptr(), tab.chunk_off.data_ptr(), tab.n_chunks,
+         sumsq.data_ptr(), _stream())
+    call("octmae_mt_finish_norm", sumsq.data_ptr(), tab.n_tensors, float(max_norm) if max_norm is not None else 0.0,
+         out.data_ptr(), out.data_ptr() + 4, _stream())
+    return out[0], out[1]
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self._tables = {}
+        self._grad_scale: Optional[torch.Tensor] = None   # device scalar multiplied into every gradient
+
+    def set_grad_scale(self, scale: Optional[torch.Tensor]):
+        self._grad_scale = scale
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Gradients are views of one arena: they are zeroed in place, never detached."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            for p in ps:
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            group.setdefault("_step", 0)
+            group["_step"] += 1
+            for p in ps:
+                self.state[p]["step"] = group["_step"]
+            key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
+            tab = self._tables.get(gi)
+            if tab is None or tab.key != key:
+                tab = _MultiTensorTable([p.data for p in ps], [p.grad for p in ps], [self.state[p]["exp_avg"] for p in ps],
+                                        [self.state[p]["exp_avg_sq"] for p in ps])
+                self._tables[gi] = tab
+            b1, b2 = group["betas"]
+            gs = self._grad_scale
+            call("octmae_mt_adamw", tab.table.data_ptr(), tab.chunk_tensor.data_ptr(), tab.chunk_off.data_ptr(), tab.n_chunks,
+                 gs.data_ptr() if gs is not None else None, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                 float(group["weight_decay"]), int(group["_step"]), _stream())
+        return loss

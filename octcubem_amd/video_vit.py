@@ -1,0 +1,199 @@
+"""Drop-in building blocks: same constructor arguments, attributes, parameter names and forward signatures
+as the reference's ``custom_util/video_vit.py`` (PatchEmbed :22-83, Attention :86-138, Block :141-184) and timm's
+``Mlp`` -- computed by the hand-written gfx950 kernels behind liboctmae.so.
+
+The nn.Conv3d / nn.Linear / nn.LayerNorm children are PARAMETER CONTAINERS only (they keep the reference's
+state_dict keys and initialisers); their own forward is never used.  GPU only, no fallback.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .arena import get_arena
+
+
+def to_2tuple(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per sample (timm DropPath): identity when drop_prob == 0 or in eval mode."""
+
+    def __init__(self, drop_prob: float = 0.0):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1 - self.drop_prob
+        shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+        return x.div(keep) * (keep + torch.rand(shape, dtype=x.dtype, device=x.device)).floor_()
+
+
+class PatchEmbed(nn.Module):
+    """Image to Patch Embedding -- Conv3d(k = s = (t_patch, p, p)) evaluated as gather + MFMA GEMM."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, frames=32, t_patch_size=4):
+        super().__init__()
+        if isinstance(img_size, int):
+            img_size = (img_size, img_size)
+        img_size = to_2tuple(img_size)
+        patch_size = to_2tuple(patch_size)
+        assert img_size[1] % patch_size[1] == 0
+        assert img_size[0] % patch_size[0] == 0
+        assert frames % t_patch_size == 0
+        self.num_patches = (img_size[1] // patch_size[1]) * (img_size[0] // patch_size[0]) * (frames // t_patch_size)
+        self.input_size = (frames // t_patch_size, img_size[0] // patch_size[0], img_size[1] // patch_size[1])
+        self.img_size = img_size
+        self.patch_size = patch_size
+        self.frames = frames
+        self.t_patch_size = t_patch_size
+        self.grid_size = img_size[0] // patch_size[0]
+        self.t_grid_size = frames // t_patch_size
+        kernel_size = [t_patch_size] + list(patch_size)
+        self.proj = nn.Conv3d(in_chans, embed_dim, kernel_size=kernel_size, stride=kernel_size)
+        self._views = None
+
+    def _v(self):
+        arena = get_arena(self)
+        if self._views is None or self._views[0] is not arena:
+            w, b = self.proj.weight, self.proj.bias
+            object.__setattr__(self, "_views", (arena, arena.lp_view(w, shape=(w.shape[0], -1)), arena.f32_view(b),
+                                                lambda: arena.grad_view(w), lambda: arena.grad_view(b)))
+        return self._views
+
+    def embed_tokens(self, x, ids_keep=None):
+        """Embeds only the tokens listed in ids_keep [B, nkeep] (all tokens when None) -> bf16 [B*nkeep, D]."""
+        B, C, T, H, W = x.shape
+        assert H == self.img_size[0] and W == self.img_size[1], \
+            f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
+        assert T % self.t_patch_size == 0
+        _, w_lp, b32, gw, gb = self._v()
+        L = (T // self.t_patch_size) * self.input_size[1] * self.input_size[2]
+        nkeep = L if ids_keep is None else ids_keep.shape[1]
+        return ops.PatchEmbedFn.apply(x.contiguous(), ids_keep, w_lp, b32, gw, gb, self.t_patch_size, self.patch_size[0], nkeep,
+                                      self.proj.weight, self.proj.bias)
+
+    def forward(self, x):
+        B, C, T, H, W = x.shape
+        tok = self.embed_tokens(x)
+        return tok.view(B, T // self.t_patch_size, self.input_size[1] * self.input_size[2], -1)   # [N, T, H*W, C]
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0, input_size=(4, 14, 14)):
+        super().__init__()
+        assert dim % num_heads == 0, "dim should be divisible by num_heads"
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        if head_dim not in (32, 64):
+            raise NotImplementedError("the gfx950 attention kernels are built for head_dim 32 and 64")
+        if qk_scale is not None and abs(qk_scale - head_dim ** -0.5) > 1e-12:
+            raise NotImplementedError("qk_scale other than head_dim**-0.5")
+        self.scale = qk_scale or head_dim ** -0.5
+        self.q = nn.Linear(dim, dim, bias=qkv_bias)
+        self.k = nn.Linear(dim, dim, bias=qkv_bias)
+        self.v = nn.Linear(dim, dim, bias=qkv_bias)
+        assert attn_drop == 0.0  # do not use
+        assert proj_drop == 0.0, "proj_drop is not supported on the fused path (the reference trains with drop=0)"
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.input_size = input_size
+        assert input_size[1] == input_size[2]
+        self._views = None
+
+    def _v(self):
+        arena = get_arena(self)
+        if self._views is None or self._views[0] is not arena:
+            q, k, v, pr = self.q, self.k, self.v, self.proj
+            D = q.weight.shape[0]
+            if not arena.fused_ok(q.weight, k.weight, v.weight):
+                raise RuntimeError("q/k/v weights are not adjacent in the arena")
+            has_b = q.bias is not None
+            if has_b and not arena.fused_ok(q.bias, k.bias, v.bias):
+                raise RuntimeError("q/k/v biases are not adjacent in the arena")
+            wqkv = arena.lp_view(q.weight, v.weight, (3 * D, D))
+            bqkv = arena.f32_view(q.bias, v.bias, (3 * D,)) if has_b else None
+            wproj = arena.lp_view(pr.weight)
+            bproj = arena.f32_view(pr.bias) if pr.bias is not None else None
+
+            def grads():
+                return (arena.grad_view(q.weight, v.weight, (3 * D, D)),
+                        arena.grad_view(q.bias, v.bias, (3 * D,)) if has_b else None,
+                        arena.grad_view(pr.weight), arena.grad_view(pr.bias) if pr.bias is not None else None)
+            params = [q.weight, k.weight, v.weight, pr.weight] + ([q.bias, k.bias, v.bias] if has_b else []) + \
+                     ([pr.bias] if pr.bias is not None else [])
+            object.__setattr__(self, "_views", (arena, wqkv, bqkv, wproj, bproj, grads, tuple(params)))
+        return self._views
+
+    def forward(self, x, residual=None):
+        """x: [B, N, C] (LayerNorm output).  With ``residual`` (fp32 [B,N,C]) returns residual + attn(x) in fp32."""
+        _, wqkv, bqkv, wproj, bproj, grads, params = self._v()
+        return ops.AttentionFn.apply(x, residual, wqkv, bqkv, wproj, bproj, grads, self.num_heads, *params)
+
+
+class Mlp(nn.Module):
+    """timm.models.vision_transformer.Mlp: fc1 -> act -> drop -> fc2 -> drop (act = exact-erf GELU)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        if act_layer is not nn.GELU:
+            raise NotImplementedError("only nn.GELU is fused into the fc1 epilogue")
+        assert drop == 0.0, "dropout is not supported on the fused path (the reference trains with drop=0)"
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+        self._views = None
+
+    def _v(self):
+        arena = get_arena(self)
+        if self._views is None or self._views[0] is not arena:
+            f1, f2 = self.fc1, self.fc2
+
+            def grads():
+                return (arena.grad_view(f1.weight), arena.grad_view(f1.bias), arena.grad_view(f2.weight), arena.grad_view(f2.bias))
+            object.__setattr__(self, "_views", (arena, arena.lp_view(f1.weight), arena.f32_view(f1.bias), arena.lp_view(f2.weight),
+                                                arena.f32_view(f2.bias), grads, (f1.weight, f1.bias, f2.weight, f2.bias)))
+        return self._views
+
+    def forward(self, x, residual=None):
+        _, w1, b1, w2, b2, grads, params = self._v()
+        return ops.MlpFn.apply(x, residual, w1, b1, w2, b2, grads, *params)
+
+
+def layer_norm(norm: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
+    """fp32 [.., D] -> bf16 LayerNorm output using `norm`'s weight / bias / eps."""
+    return ops.LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps)
+
+
+class Block(nn.Module):
+    """Transformer Block with specified Attention function (pre-norm residual, video_vit.py:181-184).
+    The residual stream is fp32; both residual adds are fused into GEMM epilogues."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, qk_scale=None, drop=0.0, attn_drop=0.0, drop_path=0.0,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm, attn_func=Attention):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = attn_func(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        mlp_hidden_dim = int(dim * mlp_ratio)
+        self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer, drop=drop)
+
+    def forward(self, x):
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        if isinstance(self.drop_path, nn.Identity) or not self.training:
+            x = self.attn(layer_norm(self.norm1, x), residual=x)
+            x = self.mlp(layer_norm(self.norm2, x), residual=x)
+        else:   # stochastic depth: the branch output has to exist on its own
+            x = x + self.drop_path(self.attn(layer_norm(self.norm1, x)).float())
+            x = x + self.drop_path(self.mlp(layer_norm(self.norm2, x)).float())
+        return x

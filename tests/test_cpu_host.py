@@ -1,0 +1,135 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol include/octmae.h declares, host logic of the
+drop-in modules (constructor contract, state_dict keys, schedules, grouping), loud failure without a GPU."""
+import ctypes
+import math
+import os
+import re
+
+import pytest
+import torch
+
+from oracle import mae3d_ref as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "octmae.h")).read()
+    return sorted(set(re.findall(r"\bint\s+(octmae_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from octcubem_amd import _lib
+    lib = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), s
+        assert s in _lib.SIGNATURES, f"{s} declared in octmae.h but not bound in _lib.SIGNATURES"
+    assert set(_lib.SIGNATURES) == set(syms)
+    assert lib.octmae_abi_version() == 1 and lib.octmae_mt_chunk_elems() == 65536
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    from octcubem_amd import _lib
+    lib = _lib.load()
+    # NULL pointers / bad sizes are rejected before any launch
+    assert lib.octmae_gemm_bf16(None, None, None, None, None, None, 8, 8, 8, 8, 8, 8, 0, 0, 0, 0, 1, None) == -1
+    assert lib.octmae_attn_fwd(None, None, None, 1, 1, 1, 64, 0.125, None) == -1
+    assert lib.octmae_layernorm_fwd(None, None, None, None, None, None, 1, 64, 1e-6, None) == -1
+    assert lib.octmae_random_masking_ids(None, None, None, None, None, 1, 8, 2, None) == -1
+    with pytest.raises(_lib.OctmaeError):
+        _lib.call("octmae_cast_f32_bf16", None, None, 8, None)
+
+
+def test_model_contract_and_state_dict_keys():
+    from octcubem_amd import models_mae
+    from functools import partial
+    cfg = O.MAEConfig(input_size=64, in_chans=1, embed_dim=128, depth=2, num_heads=2, decoder_embed_dim=64, decoder_depth=2,
+                      decoder_num_heads=2, num_frames=12, t_patch_size=3, pred_t_dim=12, high_res_input_size=128)
+    m = models_mae.MaskedAutoencoderViT(input_size=64, patch_size=16, in_chans=1, embed_dim=128, depth=2, num_heads=2,
+                                        decoder_embed_dim=64, decoder_depth=2, decoder_num_heads=2,
+                                        norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_frames=12, t_patch_size=3,
+                                        sep_pos_embed=True, cls_embed=True, pred_t_dim=12, high_res_input_size=128)
+    shapes = O.param_shapes(cfg)
+    sd = m.state_dict()
+    assert set(sd) == set(shapes)
+    assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in shapes)
+    # attributes downstream reference code reads (video_vit.py:49-67, models_mae…:83-84,503-507)
+    pe = m.patch_embed
+    assert (pe.num_patches, pe.input_size, pe.patch_size, pe.grid_size, pe.t_grid_size, pe.frames, pe.t_patch_size) == \
+        (64, (4, 4, 4), (16, 16), 4, 4, 12, 3)
+    assert m.t_pred_patch_size == 3 and m.high_res_input_size == (4, 8, 8)
+    # the flash-layout checkpoint keys are accepted (reverse of the reference's remap, models_mae…:693-724)
+    P = O.init_params(cfg, seed=1)
+    flash = {}
+    for k, v in P.items():
+        mm = re.match(r"(.*blocks\.\d+)\.attn\.(q|k|v)\.(weight|bias)$", k)
+        if mm:
+            continue
+        flash[k.replace(".attn.proj.", ".mixer.out_proj.")] = v
+    for pre in [f"blocks.{i}" for i in range(2)] + [f"decoder_blocks.{i}" for i in range(2)]:
+        for kind in ("weight", "bias"):
+            flash[f"{pre}.mixer.Wqkv.{kind}"] = torch.cat([P[f"{pre}.attn.{n}.{kind}"] for n in "qkv"], 0)
+    res = m.load_state_dict_to_backbone(flash, strict=True)
+    for k in P:
+        assert torch.equal(m.state_dict()[k], P[k]), k
+    # patchify / unpatchify round trip (visualiser helpers)
+    x = torch.rand(2, 1, 12, 64, 64)
+    assert torch.equal(m.unpatchify(m.patchify(x)), x)
+    assert torch.allclose(m.patchify(x), O.patchify(x, cfg))
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from octcubem_amd import models_mae
+    from functools import partial
+    m = models_mae.MaskedAutoencoderViT(input_size=64, patch_size=16, in_chans=1, embed_dim=128, depth=1, num_heads=2,
+                                        decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=2,
+                                        norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_frames=6, t_patch_size=3,
+                                        sep_pos_embed=True, cls_embed=True, pred_t_dim=6, high_res_input_size=128)
+    with pytest.raises(RuntimeError, match="GPU only|no CPU fallback|cuda"):
+        m(torch.rand(1, 1, 6, 64, 64))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "octcubem_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("the oracle", "").replace("oracle's", ""), fn
+
+
+def test_lr_schedule_and_weight_decay_groups():
+    from octcubem_amd import lr_sched, misc, models_mae
+
+    class A: pass
+    a = A(); a.lr = 1.6e-3; a.min_lr = 1e-6; a.warmup_epochs = 5; a.epochs = 50
+
+    class Opt:
+        def __init__(self): self.param_groups = [{"lr": 0.0}, {"lr": 0.0, "lr_scale": 0.5}]
+    for e in (0.0, 0.37, 4.999, 5.0, 17.3, 49.99):
+        o = Opt()
+        lr = lr_sched.adjust_learning_rate(o, e, a)
+        assert abs(lr - O.cosine_lr(e, 1.6e-3, 1e-6, 5, 50)) < 1e-15
+        assert o.param_groups[0]["lr"] == lr and o.param_groups[1]["lr"] == lr * 0.5
+    from functools import partial
+    m = models_mae.MaskedAutoencoderViT(input_size=64, patch_size=16, in_chans=1, embed_dim=128, depth=1, num_heads=2,
+                                        decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=2,
+                                        norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_frames=6, t_patch_size=3,
+                                        sep_pos_embed=True, cls_embed=True, pred_t_dim=6, high_res_input_size=128)
+    groups = misc.add_weight_decay(m, 0.05)
+    names = {id(p): n for n, p in m.named_parameters()}
+    nd, d = O.weight_decay_groups([(n, tuple(p.shape)) for n, p in m.named_parameters()], 0.05)
+    assert [names[id(p)] for p in groups[0]["params"]] == nd and [names[id(p)] for p in groups[1]["params"]] == d
+    assert groups[0]["weight_decay"] == 0.0 and groups[1]["weight_decay"] == 0.05
+
+
+def test_arena_ordering_makes_qkv_adjacent():
+    from octcubem_amd.arena import _ordered
+    names = ["a.norm1.weight", "a.attn.q.weight", "a.attn.q.bias", "a.attn.k.weight", "a.attn.k.bias", "a.attn.v.weight",
+             "a.attn.v.bias", "a.attn.proj.weight", "a.attn.proj.bias"]
+    out = [n for n, _ in _ordered([(n, None) for n in names])]
+    assert out == ["a.norm1.weight", "a.attn.q.weight", "a.attn.k.weight", "a.attn.v.weight", "a.attn.q.bias", "a.attn.k.bias",
+                   "a.attn.v.bias", "a.attn.proj.weight", "a.attn.proj.bias"]

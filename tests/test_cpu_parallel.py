@@ -1,0 +1,105 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel path: FlatGradReducer all-reduces slices of a flat gradient arena as
+parameters report their gradients, averages over ranks, handles parameters that never receive a gradient, skips the
+exchange on accumulation micro-steps, and NativeScalerWithGradNormCount drives it in the right order.
+The arena here is a small stand-in with the attributes the reducer reads (the real arena lives in HBM)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class FakeArena:
+    def __init__(self, shapes, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.entries = []
+        off = 0
+        self.params = []
+        for i, s in enumerate(shapes):
+            n = int(torch.tensor(s).prod())
+            self.entries.append([f"p{i}", None, off, n])
+            off += (n + 63) // 64 * 64
+        self.total = off
+        self.flat = torch.randn(self.total, generator=g)
+        self.grad = torch.zeros(self.total)
+        for e, s in zip(self.entries, shapes):
+            p = torch.nn.Parameter(self.flat[e[2]:e[2] + e[3]].view(s))
+            p.grad = self.grad[e[2]:e[2] + e[3]].view(s)
+            e[1] = p
+            self.params.append(p)
+        self.entries = [tuple(e) for e in self.entries]
+
+
+class FakeModel:
+    def __init__(self, arena):
+        self.arena = arena
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from octcubem_amd import ops
+    from octcubem_amd.parallel import FlatGradReducer
+    shapes = [(40, 30), (30,), (1, 1, 16), (500,), (64, 64), (7,)]
+    arena = FakeArena(shapes, seed=100 + rank)
+    model = FakeModel(arena)
+    red = FlatGradReducer(model, n_chunks=3)
+    red.broadcast_parameters(0)
+    flat0 = arena.flat.clone()
+    # --- step 1: accumulation micro-step (no exchange), then a sync step; param 5 never gets a gradient
+    gen = torch.Generator().manual_seed(7 + rank)
+    local = [torch.randn(s, generator=gen) for s in shapes]
+    red.begin_backward(sync=False)
+    for p, g in zip(arena.params[:5], local[:5]):
+        p.grad.add_(g); ops.notify_grad_ready([p])
+    red.finish()
+    after_micro = arena.grad.clone()
+    red.begin_backward(sync=True)
+    for p, g in zip(reversed(arena.params[:5]), reversed(local[:5])):      # backward order
+        p.grad.add_(g); ops.notify_grad_ready([p])
+    red.finish()
+    out = {"rank": rank, "flat0": flat0, "after_micro": after_micro, "grad": arena.grad.clone(), "local": local,
+           "offsets": [(e[2], e[3]) for e in arena.entries]}
+    # --- autograd-hook route (PyTorch-side parameters): backward through real autograd
+    arena.grad.zero_()
+    red.begin_backward(sync=True)
+    loss = sum((p * (rank + 1)).sum() for p in arena.params[:3])
+    loss.backward()
+    red.finish()
+    out["grad_hook"] = arena.grad.clone()
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_flat_grad_reducer_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=100) for _ in range(2)], key=lambda o: o["rank"])
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    a, b = outs
+    assert torch.equal(a["flat0"], b["flat0"])                             # broadcast made the weights identical
+    for o in outs:                                                          # micro-step: purely local
+        for (off, n), g in zip(o["offsets"][:5], o["local"][:5]):
+            assert torch.equal(o["after_micro"][off:off + n], g.flatten())
+    assert torch.allclose(a["grad"], b["grad"], atol=0, rtol=0)             # all ranks hold the same reduced gradient
+    for i, (off, n) in enumerate(a["offsets"]):
+        exp = torch.zeros(n) if i == 5 else (2 * a["local"][i] + 2 * b["local"][i]).flatten() / 2
+        assert torch.allclose(a["grad"][off:off + n], exp, atol=1e-6), i
+    assert torch.equal(a["grad_hook"], b["grad_hook"])
+    for i, (off, n) in enumerate(a["offsets"]):
+        exp = torch.full((n,), 1.5) if i < 3 else torch.zeros(n)
+        assert torch.allclose(a["grad_hook"][off:off + n], exp), i

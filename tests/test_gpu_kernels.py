@@ -1,0 +1,312 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (ctypes) -- `pytest -m gpu` on an MI355X.
+
+References: plain PyTorch fp32/fp64 math on the SAME bf16-rounded operands (floating-point kernels), the CPU
+oracle (oracle/mae3d_ref.py) and the committed golden vectors (integer work: bit-exact).
+Tolerances are stated at each check; bf16 outputs carry one rounding (2^-9 relative) on top of fp32 accumulation.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from octcubem_amd import ops, optim as foptim
+    from octcubem_amd._lib import call
+from oracle import mae3d_ref as O
+
+DEV = "cuda"
+BF16 = torch.bfloat16
+
+
+def rel(a, b):
+    a = a.double().flatten(); b = b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def bf(x):
+    return x.to(BF16)
+
+
+# ------------------------------------------------------------------------------------------------ hardware layout pins
+def test_probe_mfma_lane_map():
+    """v_mfma_f32_32x32x16_bf16: lane l (r=l&31, h=l>>5) holds A[r][8h+j], B[8h+j][r]; D reg g = D[(g&3)+8(g>>2)+4h][r]."""
+    g = torch.Generator().manual_seed(0)
+    A = torch.randint(-3, 4, (32, 16), generator=g).float()
+    Bm = torch.randint(-3, 4, (16, 32), generator=g).float()      # asymmetric, exact in bf16
+    af = torch.empty(64, 8); bfr = torch.empty(64, 8)
+    for l in range(64):
+        r, h = l & 31, l >> 5
+        af[l] = A[r, 8 * h:8 * h + 8]
+        bfr[l] = Bm[8 * h:8 * h + 8, r]
+    d = torch.empty(64, 16, device=DEV)
+    call("octmae_probe_mfma32", bf(af).to(DEV).data_ptr(), bf(bfr).to(DEV).data_ptr(), d.data_ptr(), None)
+    torch.cuda.synchronize()
+    D = A @ Bm
+    exp = torch.empty(64, 16)
+    for l in range(64):
+        r, h = l & 31, l >> 5
+        for gi in range(16):
+            exp[l, gi] = D[(gi & 3) + 8 * (gi >> 2) + 4 * h, r]
+    assert torch.equal(d.cpu(), exp)
+
+
+def test_probe_ds_read_tr_lane_map():
+    """ds_read_b64_tr_b16: in a 16-lane group lane 4q+p addresses row q, cols 4p..4p+3; lane i receives column i of rows 0..3."""
+    tile = torch.arange(256, dtype=torch.float32).view(16, 16)
+    out = torch.empty(64, 4, dtype=BF16, device=DEV)
+    call("octmae_probe_trread", bf(tile).to(DEV).data_ptr(), out.data_ptr(), None)
+    torch.cuda.synchronize()
+    exp = torch.empty(64, 4)
+    for l in range(64):
+        grp, i = l >> 4, l & 15
+        for q in range(4):
+            exp[l, q] = tile[4 * grp + q, i]
+    assert torch.equal(out.float().cpu(), exp)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+GEMM_SHAPES = [(128, 128, 64), (256, 384, 128), (200, 136, 72), (1281, 384, 128), (64, 64, 64), (5121, 192, 64), (130, 768, 512)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_forward_epilogues(M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = bf(torch.randn(M, K, generator=g)).to(DEV)
+    w = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(M, N, generator=g).to(DEV)
+    ref = (x.double() @ w.double().t() + b.double())
+    y32 = ops.linear_fwd(x, w, b, "f32")
+    assert rel(y32, ref) < 2e-6                        # fp32 accumulate of exact bf16 products
+    y16 = ops.linear_fwd(x, w, b, "bf16")
+    assert rel(y16, ref) < 3e-3                        # one bf16 rounding
+    assert torch.equal(y16, y32.to(BF16))
+    ynb = ops.linear_fwd(x, w, None, "f32")
+    assert rel(ynb, x.double() @ w.double().t()) < 2e-6
+    yr = ops.linear_fwd(x, w, b, "resid", res=res)
+    assert rel(yr, ref + res.double()) < 2e-6
+    pre, act = ops.linear_fwd(x, w, b, "gelu")
+    assert torch.equal(pre, y16)
+    ref_act = torch.nn.functional.gelu(pre.double())
+    assert rel(act, ref_act) < 3e-3
+    assert float((act.double() - ref_act).abs().max()) < 2e-2 * float(ref_act.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_dgrad_and_wgrad(M, N, K):
+    g = torch.Generator().manual_seed(M + N * 3)
+    x = bf(torch.randn(M, K, generator=g)).to(DEV)
+    w = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
+    dy = bf(torch.randn(M, N, generator=g)).to(DEV)
+    pre = bf(torch.randn(M, K, generator=g)).to(DEV)
+    dx_ref = dy.double() @ w.double()
+    dx = ops.linear_dgrad(dy, w)
+    assert rel(dx, dx_ref) < 3e-3
+    xg = pre.double().requires_grad_(True)
+    torch.nn.functional.gelu(xg).backward(dx_ref)
+    dxg = ops.linear_dgrad(dy, w, pre=pre)
+    assert rel(dxg, xg.grad) < 3e-3
+    gw0 = torch.randn(N, K, generator=g).to(DEV)
+    gw = gw0.clone()
+    ops.linear_wgrad_accum(dy, x, gw)
+    gw_ref = gw0.double() + dy.double().t() @ x.double()
+    assert rel(gw, gw_ref) < 1e-5                       # fp32 accumulate (+ fp32 atomics across split-K slices)
+    gw2 = gw0.clone()
+    ops._gemm(dy, x, gw2, N, K, M, N, K, K, 1, 1, ops.EPI_ACCUM, splitk=1)   # deterministic single-slice path
+    assert rel(gw2, gw_ref) < 1e-5
+
+
+def test_gemm_rejects_bad_arguments():
+    x = torch.zeros(8, 12, dtype=BF16, device=DEV)      # K = 12 not a multiple of 8
+    w = torch.zeros(8, 12, dtype=BF16, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.linear_fwd(x, w, None, "bf16")
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm / colsum / cast
+@pytest.mark.parametrize("M,D", [(7, 64), (1281, 1024), (300, 512), (33, 128), (5, 2048), (9, 768)])
+def test_layernorm_fwd_bwd(M, D):
+    g = torch.Generator().manual_seed(D + M)
+    x = (torch.randn(M, D, generator=g) * 2 + 0.5).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(D, generator=g)).to(DEV)
+    dy = bf(torch.randn(M, D, generator=g)).to(DEV)
+    dres = torch.randn(M, D, generator=g).to(DEV)
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-6)
+    xd = x.double().requires_grad_(True); gd = gamma.double().requires_grad_(True); bd = beta.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xd, (D,), gd, bd, 1e-6)
+    assert rel(y, yr) < 3e-3
+    assert rel(mean, x.double().mean(1)) < 1e-5 and rel(rstd, (x.double().var(1, unbiased=False) + 1e-6).rsqrt()) < 1e-5
+    yr.backward(dy.double())
+    dgamma = torch.zeros(D, device=DEV); dbeta = torch.zeros(D, device=DEV); dxsum = torch.zeros(D, device=DEV)
+    dx, dxb = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=dres, want_bf16=True, dxsum=dxsum)
+    dx_ref = xd.grad + dres.double()
+    assert rel(dx, dx_ref) < 2e-5
+    assert torch.equal(dxb, dx.to(BF16))
+    assert rel(dgamma, gd.grad) < 1e-4 and rel(dbeta, bd.grad) < 1e-4
+    assert rel(dxsum, dx_ref.sum(0)) < 1e-4
+    dx2, none = ops.layernorm_bwd(dy, x, mean, rstd, gamma, None, None)
+    assert none is None and rel(dx2, xd.grad) < 2e-5
+
+
+def test_colsum_and_cast():
+    g = torch.Generator().manual_seed(3)
+    for M, N in [(1, 64), (1000, 192), (5121, 768), (77, 8)]:
+        a = torch.randn(M, N, generator=g).to(DEV)
+        out = torch.ones(N, device=DEV)
+        ops.colsum_accum(a, out)
+        assert rel(out, 1 + a.double().sum(0)) < 1e-5
+        ab = bf(a)
+        out2 = torch.zeros(N, device=DEV)
+        ops.colsum_accum(ab, out2)
+        assert rel(out2, ab.double().sum(0)) < 1e-5
+    for n in [1, 7, 8, 1000, 65536 * 3 + 5]:
+        a = torch.randn(n, generator=g).to(DEV)
+        assert torch.equal(ops.cast_bf16(a), a.to(BF16))
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attn_ref(qkv, B, N, H, HD):
+    q, k, v = qkv.double().view(B, N, 3, H, HD).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-2, -1)) * HD ** -0.5
+    p = s.softmax(-1)
+    return (p @ v).transpose(1, 2).reshape(B * N, H * HD), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("HD", [64, 32])
+@pytest.mark.parametrize("N", [1, 31, 64, 65, 129, 200, 1281])
+def test_attention_fwd_bwd(HD, N):
+    B, H = 2, 3
+    g = torch.Generator().manual_seed(N * 3 + HD)
+    qkv = bf(torch.randn(B * N, 3 * H * HD, generator=g)).to(DEV)
+    do = bf(torch.randn(B * N, H * HD, generator=g)).to(DEV)
+    o, lse = ops.attn_fwd(qkv, B, N, H, HD, HD ** -0.5)
+    qd = qkv.double().requires_grad_(True)
+    o_ref, lse_ref = attn_ref(qd, B, N, H, HD)
+    assert rel(o, o_ref) < 4e-3                                   # bf16 P and bf16 output
+    assert float((lse.double() - lse_ref).abs().max()) < 2e-3
+    o_ref.backward(do.double())
+    dqkv = ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, HD ** -0.5)
+    got = dqkv.double().view(B, N, 3, H * HD); ref = qd.grad.view(B, N, 3, H * HD)
+    for i, name in enumerate("qkv"):
+        assert rel(got[:, :, i], ref[:, :, i]) < 1.5e-2, name     # bf16 P, dS and outputs
+
+
+@pytest.mark.parametrize("HD", [64, 32])
+def test_attention_online_softmax_rescale_branch(HD):
+    """Force the running max to jump at a late key tile (one query/key pair with a huge score)."""
+    B, H, N = 1, 2, 300
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B * N, 3, H, HD, generator=g)
+    x[17, 0, 0] *= 8.0
+    x[257, 1, 0] = x[17, 0, 0]            # key 257 (5th tile) aligned with query 17
+    qkv = bf(x.reshape(B * N, -1)).to(DEV)
+    o, lse = ops.attn_fwd(qkv, B, N, H, HD, HD ** -0.5)
+    o_ref, lse_ref = attn_ref(qkv, B, N, H, HD)
+    assert torch.isfinite(o).all()
+    assert rel(o, o_ref) < 5e-3 and float((lse.double() - lse_ref).abs().max()) < 5e-2
+
+
+# ------------------------------------------------------------------------------------------------ masking (bit-exact)
+def test_random_masking_bit_exact_golden(golden_dir):
+    m = np.load(os.path.join(golden_dir, "masking.npz"))
+    noise = torch.from_numpy(m["noise_free"]).to(DEV)
+    mask, ids_restore, ids_keep, ids_shuffle = ops.random_masking_ids(noise, 1280, want_shuffle=True)
+    assert torch.equal(ids_restore.cpu(), torch.from_numpy(m["ids_restore_free"]))
+    assert torch.equal(ids_keep.cpu(), torch.from_numpy(m["ids_keep_free"]))
+    assert torch.equal(mask.cpu(), torch.from_numpy(m["mask_free"]))
+    assert torch.equal(ids_shuffle.cpu(), torch.argsort(noise.cpu(), dim=1, stable=True))
+    mask9, _, keep9 = ops.random_masking_ids(noise, int(5120 * (1 - 0.9)))
+    assert torch.equal(keep9.cpu(), torch.from_numpy(m["ids_keep_free_r90"])) and torch.equal(mask9.cpu(), torch.from_numpy(m["mask_free_r90"]))
+    # rows with exact ties: equal to the stable order (the oracle's definition), a valid permutation
+    nt = torch.from_numpy(m["noise_tie"]).to(DEV)
+    mk, ir, ik, ish = ops.random_masking_ids(nt, 1280, want_shuffle=True)
+    os_, or_, ok_, om_ = O.masking_indices(nt.cpu(), 0.75)
+    assert torch.equal(ish.cpu(), os_) and torch.equal(ir.cpu(), or_) and torch.equal(ik.cpu(), ok_) and torch.equal(mk.cpu(), om_)
+
+
+@pytest.mark.parametrize("L,keep", [(1, 1), (2, 0), (64, 16), (1000, 250), (8192, 2048), (5120, 0), (5120, 5120), (16384, 100)])
+def test_random_masking_edge_sizes(L, keep):
+    g = torch.Generator().manual_seed(L)
+    noise = torch.rand(3, L, generator=g)
+    noise[0, : L // 2] = noise[0, L - L // 2:]              # many ties
+    if L > 4:
+        noise[1, 3] = -0.0; noise[1, 4] = 0.0; noise[2, 1] = -1.5
+    mask, ids_restore, ids_keep, ids_shuffle = ops.random_masking_ids(noise.to(DEV), keep, want_shuffle=True)
+    exp = torch.argsort(noise, dim=1, stable=True)
+    assert torch.equal(ids_shuffle.cpu(), exp)
+    assert torch.equal(ids_restore.cpu(), torch.argsort(exp, dim=1))
+    assert torch.equal(ids_keep.cpu(), exp[:, :keep])
+    assert float(mask.sum()) == 3 * (L - keep)
+
+
+# ------------------------------------------------------------------------------------------------ token plumbing
+def test_patch_gather_and_embed_vs_conv3d():
+    cfg = O.MAEConfig(input_size=64, in_chans=1, embed_dim=128, num_frames=12, t_patch_size=3, pred_t_dim=12, high_res_input_size=128)
+    g = torch.Generator().manual_seed(2)
+    imgs = torch.rand(2, 1, 12, 64, 64, generator=g)
+    w = torch.randn(128, 1, 3, 16, 16, generator=g) * 0.05
+    b = torch.randn(128, generator=g) * 0.1
+    ids = torch.stack([torch.randperm(64, generator=g)[:16] for _ in range(2)])
+    pat = ops.patch_gather(imgs.to(DEV), ids.to(DEV), 3, 16, 16)
+    full = O.patchify(imgs, cfg)                                  # (u,p,q,c) == (c,u,p,q) when C == 1
+    exp = torch.gather(full, 1, ids.unsqueeze(-1).expand(-1, -1, 768)).reshape(32, 768)
+    assert torch.equal(pat.cpu(), exp.to(BF16))
+    tok = ops.linear_fwd(pat, bf(w.view(128, -1)).to(DEV), b.to(DEV), "f32")
+    ref = O.patch_embed(imgs.to(BF16).double(), bf(w).double(), b.double(), cfg)
+    ref = torch.gather(ref, 1, ids.unsqueeze(-1).expand(-1, -1, 128)).reshape(32, 128)
+    assert rel(tok, ref) < 1e-5
+    # multi-channel ordering (c,u,py,px)
+    imgs3 = torch.rand(1, 2, 3, 16, 32, generator=g)
+    pat3 = ops.patch_gather(imgs3.to(DEV), None, 3, 16, 2)
+    exp3 = imgs3.view(1, 2, 3, 16, 2, 16).permute(0, 4, 1, 2, 3, 5).reshape(2, -1)
+    assert torch.equal(pat3.cpu(), exp3.to(BF16))
+
+
+@pytest.mark.parametrize("norm_pix", [False, True])
+def test_patch_mse_fwd_bwd(norm_pix):
+    cfg = O.MAEConfig(input_size=32, in_chans=1, num_frames=6, t_patch_size=3, pred_t_dim=6, high_res_input_size=64, norm_pix_loss=norm_pix)
+    g = torch.Generator().manual_seed(4)
+    imgs = torch.rand(2, 1, 6, 32, 32, generator=g)
+    L = cfg.num_patches
+    pred_full = torch.randn(2, L + 1, 768, generator=g)
+    mask = (torch.rand(2, L, generator=g) > 0.3).float()
+    pf = pred_full.to(DEV).requires_grad_(True)
+    loss_tok = ops.PatchMSEFn.apply(pf, imgs.to(DEV), None, 3, 16, norm_pix)
+    loss = (loss_tok * mask.to(DEV)).sum() / mask.sum()
+    loss.backward()
+    pr = pred_full[:, 1:].double().requires_grad_(True)
+    lref, _ = O.forward_loss(imgs.double(), pr, mask.double(), cfg)
+    lref.backward()
+    assert abs(float(loss) - float(lref)) < 1e-5 * abs(float(lref))
+    assert rel(pf.grad[:, 1:], pr.grad) < 3e-3 and float(pf.grad[:, 0].abs().max()) == 0.0     # bf16 dpred
+
+
+# ------------------------------------------------------------------------------------------------ optimizer side
+def test_fused_adamw_and_grad_norm_match_oracle(golden_dir):
+    g = torch.Generator().manual_seed(9)
+    shapes = [(128, 64), (7,), (1, 1, 64), (65536 + 3,), (300, 300)]
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g).to(DEV)) for s in shapes]
+    for p in ps:
+        p.grad = torch.randn(p.shape, generator=g).to(DEV)
+    ref_p = [p.detach().cpu().clone() for p in ps]; ref_m = [torch.zeros_like(p) for p in ref_p]; ref_v = [torch.zeros_like(p) for p in ref_p]
+    opt = foptim.FusedAdamW([{"params": ps[:2], "weight_decay": 0.0}, {"params": ps[2:], "weight_decay": 0.05}], lr=1.6e-3, betas=(0.9, 0.95))
+    from octcubem_amd import misc
+    for step in (1, 2, 3):
+        gn = misc.get_grad_norm_(ps)
+        assert abs(float(gn) - float(O.grad_norm([p.grad.cpu() for p in ps]))) < 1e-5 * float(gn)
+        opt.step()
+        for i, p in enumerate(ps):
+            wd = 0.0 if i < 2 else 0.05
+            ref_p[i], ref_m[i], ref_v[i] = O.adamw_step(ref_p[i], p.grad.cpu(), ref_m[i], ref_v[i], step, 1.6e-3, 0.9, 0.95, 1e-8, wd)
+            assert rel(p.detach(), ref_p[i]) < 1e-6
+        for p in ps:
+            p.grad = torch.randn(p.shape, generator=g).to(DEV)
+    # clip coefficient folded into the step
+    norm, coef = foptim.grad_norm_and_coef(ps, 0.5, {})
+    assert abs(float(coef) - min(1.0, 0.5 / (float(norm) + 1e-6))) < 1e-6

@@ -1,0 +1,221 @@
+"""GPU parity of the whole hot path: the HIP model (octcubem_amd.models_mae) against
+  (1) the golden vectors produced by the REAL reference (tests/golden/mae3d_small*.npz), and
+  (2) the CPU oracle on the same seeded inputs, up to the full ViT-L / 60x256x256 configuration.
+
+Tolerances (bf16 MFMA operands, fp32 accumulation / residual stream / statistics; BASELINE's target is 1e-3 rel on
+the loss): loss rel <= 1e-3 (small model) ; pred rel-L2 <= 1e-2 ; gradient rel-L2 per tensor <= 5e-2 with the
+global gradient norm within 1e-2 ; masking indices bit-exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from octcubem_amd import models_mae, misc, optim as foptim, lr_sched, engine_pretrain
+from oracle import mae3d_ref as O
+
+DEV = "cuda"
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).double().flatten().cpu(); b = torch.as_tensor(b).double().flatten().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def build(cfg: O.MAEConfig, P=None):
+    from functools import partial
+    m = models_mae.MaskedAutoencoderViT(
+        input_size=cfg.input_size, patch_size=cfg.patch_size, in_chans=cfg.in_chans, embed_dim=cfg.embed_dim, depth=cfg.depth,
+        num_heads=cfg.num_heads, decoder_embed_dim=cfg.decoder_embed_dim, decoder_depth=cfg.decoder_depth,
+        decoder_num_heads=cfg.decoder_num_heads, mlp_ratio=cfg.mlp_ratio, norm_layer=partial(torch.nn.LayerNorm, eps=cfg.ln_eps),
+        norm_pix_loss=cfg.norm_pix_loss, num_frames=cfg.num_frames, t_patch_size=cfg.t_patch_size, sep_pos_embed=True,
+        cls_embed=True, pred_t_dim=cfg.pred_t_dim, high_res_input_size=cfg.high_res_input_size)
+    if P is not None:
+        missing = m.load_state_dict(P, strict=True)
+    return m.to(DEV)
+
+
+def small(golden_dir):
+    z = np.load(os.path.join(golden_dir, "mae3d_small.npz"))
+    cfg = O.MAEConfig(**json.loads(str(z["cfg"])))
+    P = O.init_params(cfg, seed=int(z["param_seed"]), bias_std=float(z["param_bias_std"]))
+    return z, cfg, P
+
+
+def test_state_dict_keys_match_reference_layout(golden_dir):
+    z, cfg, P = small(golden_dir)
+    m = build(cfg)
+    assert set(m.state_dict().keys()) == set(O.param_shapes(cfg).keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(O.param_shapes(cfg)[k]), k
+    full = models_mae.octcube_vit_large_3dmae()
+    assert sum(p.numel() for p in full.parameters()) == 331_632_384
+
+
+def test_small_model_vs_reference_golden(golden_dir):
+    z, cfg, P = small(golden_dir)
+    m = build(cfg, P)
+    m.train()
+    imgs, noise = torch.from_numpy(z["imgs"]).to(DEV), torch.from_numpy(z["noise"]).to(DEV)
+    (loss, fl), pred, mask = m(imgs, mask_ratio=float(z["mask_ratio"]), frame_loss=True, noise=noise)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(mask.cpu(), torch.from_numpy(z["mask"]))                       # bit-exact
+    assert torch.equal(m._ids_restore.cpu(), torch.from_numpy(z["ids_restore"]))      # bit-exact
+    assert abs(float(loss) - float(z["loss"])) <= 1e-3 * float(z["loss"])
+    assert rel(pred, z["pred"]) <= 1e-2
+    assert rel(fl, z["frame_losses"]) <= 2e-3
+    sq = 0.0
+    for k, p in m.named_parameters():
+        gn = float(z[f"gnorm/{k}"])
+        g = p.grad
+        if gn == 0.0:
+            assert g is None or float(g.abs().max()) == 0.0, k
+            continue
+        ref = torch.from_numpy(z[f"grad/{k}"])
+        mine = g.cpu() if g.numel() <= 8192 else g.cpu().flatten()[::7]
+        assert rel(mine.reshape(ref.shape), ref) <= 5e-2, (k, rel(mine.reshape(ref.shape), ref))
+        sq += float(g.double().pow(2).sum())
+    total_ref = float(np.sqrt(sum(float(z[k]) ** 2 for k in z.files if k.startswith("gnorm/"))))
+    assert abs(sq ** 0.5 - total_ref) <= 1e-2 * total_ref
+
+
+def test_small_model_variants_vs_reference_golden(golden_dir):
+    z, cfg, P = small(golden_dir)
+    v = np.load(os.path.join(golden_dir, "mae3d_small_variants.npz"))
+    imgs, noise = torch.from_numpy(z["imgs"]).to(DEV), torch.from_numpy(z["noise"]).to(DEV)
+    m = build(O.MAEConfig(**{**cfg.__dict__, "norm_pix_loss": True}), P)
+    with torch.no_grad():
+        loss, pred, mask = m(imgs, mask_ratio=0.9, noise=noise)
+    assert torch.equal(mask.cpu(), torch.from_numpy(v["mask_r90"]))
+    assert abs(float(loss) - float(v["loss_normpix_r90"])) <= 1e-3 * float(v["loss_normpix_r90"])
+    assert rel(pred, v["pred_r90"]) <= 1e-2
+    # high-res (2-D / 512-style) branch through high_res_patch_embed, un-interpolated spatial table, no temporal table
+    m2 = build(cfg, P)
+    with torch.no_grad():
+        loss, pred, mask = m2(torch.from_numpy(v["imgs_hr"]).to(DEV), mask_ratio=0.75, noise=torch.from_numpy(v["noise_hr"]).to(DEV))
+    assert torch.equal(mask.cpu(), torch.from_numpy(v["mask_hr"]))
+    assert abs(float(loss) - float(v["loss_hr"])) <= 1e-3 * float(v["loss_hr"])
+    assert rel(pred, v["pred_hr"]) <= 1e-2
+
+
+def test_mid_model_vs_oracle_seeded():
+    """A mid-size configuration the oracle finishes in seconds: heads of 64 and 32, N not a multiple of 64."""
+    cfg = O.MAEConfig(input_size=96, in_chans=1, embed_dim=256, depth=3, num_heads=4, decoder_embed_dim=128, decoder_depth=2,
+                      decoder_num_heads=4, num_frames=15, t_patch_size=3, pred_t_dim=15, high_res_input_size=192)
+    P = O.init_params(cfg, seed=3, bias_std=0.02)
+    imgs = torch.rand(3, 1, 15, 96, 96, generator=torch.Generator().manual_seed(1))
+    noise = torch.rand(3, cfg.num_patches, generator=torch.Generator().manual_seed(2))
+    loss_r, pred_r, mask_r, ids_r, grads_r = O.forward_backward(P, imgs, cfg, 0.75, noise)
+    m = build(cfg, P)
+    loss, pred, mask = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
+    loss.backward()
+    assert torch.equal(mask.cpu(), mask_r) and torch.equal(m._ids_restore.cpu(), ids_r)
+    assert abs(float(loss) - float(loss_r)) <= 1e-3 * float(loss_r)
+    assert rel(pred, pred_r) <= 1e-2
+    worst = max((rel(p.grad, grads_r[k]), k) for k, p in m.named_parameters() if float(grads_r[k].abs().max()) > 0)
+    assert worst[0] <= 5e-2, worst
+
+
+def test_train_step_matches_oracle_adamw():
+    """Two optimizer steps through NativeScalerWithGradNormCount + FusedAdamW + add_weight_decay + lr schedule, vs the
+    oracle's forward/backward + AdamW restatement (grad-norm value, updated parameters)."""
+    cfg = O.MAEConfig(input_size=64, in_chans=1, embed_dim=128, depth=2, num_heads=2, decoder_embed_dim=64, decoder_depth=1,
+                      decoder_num_heads=2, num_frames=6, t_patch_size=3, pred_t_dim=6, high_res_input_size=128)
+    P = O.init_params(cfg, seed=5, bias_std=0.02)
+    m = build(cfg, P)
+    groups = misc.add_weight_decay(m, 0.05)
+    opt = foptim.FusedAdamW(groups, lr=1e-3, betas=(0.9, 0.95))
+    scaler = misc.NativeScalerWithGradNormCount(fp32=True)
+
+    class A: pass
+    a = A(); a.lr = 1e-3; a.min_lr = 0.0; a.warmup_epochs = 1; a.epochs = 10
+    nd, _ = O.weight_decay_groups([(k, tuple(v.shape)) for k, v in P.items()], 0.05)
+    nd = set(nd)
+    Pr = {k: v.clone() for k, v in P.items()}
+    Mr = {k: torch.zeros_like(v) for k, v in P.items()}; Vr = {k: torch.zeros_like(v) for k, v in P.items()}
+    for step in (1, 2):
+        imgs = torch.rand(2, 1, 6, 64, 64, generator=torch.Generator().manual_seed(10 + step))
+        noise = torch.rand(2, cfg.num_patches, generator=torch.Generator().manual_seed(20 + step))
+        lr = lr_sched.adjust_learning_rate(opt, 0.5 * step, a)
+        opt.zero_grad()
+        loss, _, _ = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
+        norm = scaler(loss, opt, parameters=m.parameters(), clip_grad=None)
+        loss_r, _, _, _, G = O.forward_backward(Pr, imgs, cfg, 0.75, noise)
+        assert abs(float(loss) - float(loss_r)) <= 2e-3 * float(loss_r)
+        assert abs(float(norm) - float(O.grad_norm(G.values()))) <= 2e-2 * float(O.grad_norm(G.values()))
+        assert abs(lr - O.cosine_lr(0.5 * step, 1e-3, 0.0, 1, 10)) < 1e-12
+        for k in Pr:
+            Pr[k], Mr[k], Vr[k] = O.adamw_step(Pr[k], G[k], Mr[k], Vr[k], step, lr, 0.9, 0.95, 1e-8, 0.0 if k in nd else 0.05)
+    sd = m.state_dict()
+    # Adam's first steps move every weight by ~lr * sign(g) whatever the gradient scale, so elements whose gradient is
+    # below the bf16 noise floor may flip: compare the UPDATE VECTORS in aggregate (cosine), not element-wise.
+    # (FusedAdamW itself is checked to 1e-6 on identical gradients in test_gpu_kernels.py.)
+    dot = sum(float(((sd[k].cpu().double() - P[k].double()) * (Pr[k].double() - P[k].double())).sum()) for k in Pr)
+    n1 = sum(float((sd[k].cpu().double() - P[k].double()).pow(2).sum()) for k in Pr) ** 0.5
+    n2 = sum(float((Pr[k].double() - P[k].double()).pow(2).sum()) for k in Pr) ** 0.5
+    assert dot / (n1 * n2) >= 0.85, dot / (n1 * n2)
+
+
+def test_engine_train_one_epoch_runs_and_learns():
+    cfg = O.MAEConfig(input_size=64, in_chans=1, embed_dim=128, depth=2, num_heads=2, decoder_embed_dim=64, decoder_depth=1,
+                      decoder_num_heads=2, num_frames=6, t_patch_size=3, pred_t_dim=6, high_res_input_size=128)
+    torch.manual_seed(0)
+    m = build(cfg)
+    opt = foptim.FusedAdamW(misc.add_weight_decay(m, 0.05), lr=1e-3, betas=(0.9, 0.95))
+    scaler = misc.NativeScalerWithGradNormCount(fp32=True)
+
+    class A: pass
+    a = A(); a.lr = 2e-3; a.min_lr = 0.0; a.warmup_epochs = 0; a.epochs = 4; a.accum_iter = 2; a.mask_ratio = 0.75; a.clip_grad = 1.0
+    g = torch.Generator().manual_seed(0)
+    base = torch.rand(1, 1, 6, 64, 64, generator=g)
+    data = [(base + 0.01 * torch.rand(2, 1, 6, 64, 64, generator=g), None) for _ in range(8)]
+    first = engine_pretrain.train_one_epoch(m, data, opt, torch.device(DEV), 0, scaler, args=a)
+    for ep in (1, 2, 3):
+        last = engine_pretrain.train_one_epoch(m, data, opt, torch.device(DEV), ep, scaler, args=a)
+    assert last["loss"] < first["loss"]
+
+
+@pytest.mark.skipif(os.environ.get("OCTMAE_SKIP_VITL", "0") == "1", reason="full-size run disabled")
+def test_vitl_full_size_forward_vs_reference_pins(golden_dir):
+    """BASELINE configuration (ViT-L, 1x60x256x256, mask 0.75) against scalar pins captured from the real reference."""
+    pins = np.load(os.path.join(golden_dir, "vitl_pins.npz"))
+    P = O.init_params(O.VIT_L, seed=0)
+    m = models_mae.octcube_vit_large_3dmae()
+    m.load_state_dict(P, strict=True)
+    m = m.to(DEV)
+    imgs = torch.rand(1, 1, 60, 256, 256, generator=torch.Generator().manual_seed(0))
+    torch.manual_seed(int(pins["noise_seed"]))
+    noise = torch.rand(1, 5120)
+    with torch.no_grad():
+        loss, pred, mask = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
+    assert torch.equal(m._ids_restore.cpu().int(), torch.from_numpy(pins["ids_restore"]))      # bit-exact at L = 5120
+    assert float(mask.sum()) == 3840.0
+    assert abs(float(loss) - float(pins["loss"])) <= 1e-3 * float(pins["loss"])
+    samp = pred.flatten()[torch.from_numpy(pins["pred_idx"]).to(DEV)]
+    assert rel(samp, pins["pred_samples"]) <= 2e-2
+    assert abs(float(pred.double().norm()) - float(pins["pred_l2"])) <= 1e-2 * float(pins["pred_l2"])
+
+
+def test_full_size_properties_batch2():
+    """Size-independent properties at BASELINE size: permutation round trip, mask count, finite loss and gradients,
+    batch independence of the forward (row b of a batch == the same volume alone)."""
+    torch.manual_seed(0)
+    m = models_mae.octcube_vit_large_3dmae().to(DEV)
+    imgs = torch.rand(2, 1, 60, 256, 256, device=DEV)
+    noise = torch.rand(2, 5120, device=DEV)
+    loss, pred, mask = m(imgs, mask_ratio=0.75, noise=noise)
+    loss.backward()
+    ir = m._ids_restore
+    assert torch.equal(torch.sort(ir, dim=1).values, torch.arange(5120, device=DEV).expand(2, -1))
+    assert float(mask.sum()) == 2 * 3840 and torch.equal(mask, (ir >= 1280).float())
+    assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    assert float(m.high_res_patch_embed.proj.weight.grad.abs().max()) == 0.0
+    with torch.no_grad():
+        l1, p1, _ = m(imgs[1:], mask_ratio=0.75, noise=noise[1:])
+    assert rel(p1, pred[1:].detach()) <= 1e-6
