@@ -51,7 +51,7 @@ using namespace octmae;
 
 extern "C" int octmae_random_masking_ids(const float* noise, long long* ids_restore, long long* ids_keep,
                                          long long* ids_shuffle, float* mask, int B, int L, int len_keep, void* stream) {
-  OCTMAE_CHECK_ARG(noise && ids_restore && ids_keep && mask);
+  OCTMAE_CHECK_ARG(noise && ids_restore && mask && (ids_keep || len_keep == 0));
   OCTMAE_CHECK_ARG(B > 0 && L > 0 && L <= 16384 && len_keep >= 0 && len_keep <= L);
   int npad = 2;
   while (npad < L) npad <<= 1;

@@ -243,8 +243,8 @@ def random_masking_ids(noise: torch.Tensor, len_keep: int, want_shuffle: bool = 
     ids_keep = torch.empty((Bn, len_keep), dtype=torch.int64, device=dev)
     ids_shuffle = torch.empty((Bn, L), dtype=torch.int64, device=dev) if want_shuffle else None
     mask = torch.empty((Bn, L), dtype=F32, device=dev)
-    call("octmae_random_masking_ids", noise.data_ptr(), ids_restore.data_ptr(), ids_keep.data_ptr(), _p(ids_shuffle), mask.data_ptr(),
-         Bn, L, len_keep, _stream())
+    call("octmae_random_masking_ids", noise.data_ptr(), ids_restore.data_ptr(), ids_keep.data_ptr() if len_keep > 0 else None, _p(ids_shuffle),
+         mask.data_ptr(), Bn, L, len_keep, _stream())
     if want_shuffle:
         return mask, ids_restore, ids_keep, ids_shuffle
     return mask, ids_restore, ids_keep

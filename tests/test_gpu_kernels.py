@@ -24,7 +24,7 @@ BF16 = torch.bfloat16
 
 
 def rel(a, b):
-    a = a.double().flatten(); b = b.double().flatten()
+    a = a.detach().double().flatten().cpu(); b = b.detach().double().flatten().cpu()
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
@@ -44,7 +44,8 @@ def test_probe_mfma_lane_map():
         af[l] = A[r, 8 * h:8 * h + 8]
         bfr[l] = Bm[8 * h:8 * h + 8, r]
     d = torch.empty(64, 16, device=DEV)
-    call("octmae_probe_mfma32", bf(af).to(DEV).data_ptr(), bf(bfr).to(DEV).data_ptr(), d.data_ptr(), None)
+    a_dev, b_dev = bf(af).to(DEV), bf(bfr).to(DEV)          # keep both alive: the call only sees raw pointers
+    call("octmae_probe_mfma32", a_dev.data_ptr(), b_dev.data_ptr(), d.data_ptr(), None)
     torch.cuda.synchronize()
     D = A @ Bm
     exp = torch.empty(64, 16)
@@ -59,7 +60,8 @@ def test_probe_ds_read_tr_lane_map():
     """ds_read_b64_tr_b16: in a 16-lane group lane 4q+p addresses row q, cols 4p..4p+3; lane i receives column i of rows 0..3."""
     tile = torch.arange(256, dtype=torch.float32).view(16, 16)
     out = torch.empty(64, 4, dtype=BF16, device=DEV)
-    call("octmae_probe_trread", bf(tile).to(DEV).data_ptr(), out.data_ptr(), None)
+    tile_dev = bf(tile).to(DEV)
+    call("octmae_probe_trread", tile_dev.data_ptr(), out.data_ptr(), None)
     torch.cuda.synchronize()
     exp = torch.empty(64, 4)
     for l in range(64):
@@ -193,8 +195,12 @@ def test_attention_fwd_bwd(HD, N):
     o_ref.backward(do.double())
     dqkv = ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, HD ** -0.5)
     got = dqkv.double().view(B, N, 3, H * HD); ref = qd.grad.view(B, N, 3, H * HD)
+    scale_ref = float(ref.norm()) / ref.numel() ** 0.5
     for i, name in enumerate("qkv"):
-        assert rel(got[:, :, i], ref[:, :, i]) < 1.5e-2, name     # bf16 P, dS and outputs
+        if float(ref[:, :, i].norm()) < 1e-9:                     # N == 1: dq = dk = 0 exactly in exact arithmetic
+            assert float(got[:, :, i].abs().max()) < 1e-5 * max(scale_ref, 1.0), name
+        else:
+            assert rel(got[:, :, i], ref[:, :, i]) < 1.5e-2, name     # bf16 P, dS and outputs
 
 
 @pytest.mark.parametrize("HD", [64, 32])

@@ -70,6 +70,7 @@ def test_small_model_vs_reference_golden(golden_dir):
     assert abs(float(loss) - float(z["loss"])) <= 1e-3 * float(z["loss"])
     assert rel(pred, z["pred"]) <= 1e-2
     assert rel(fl, z["frame_losses"]) <= 2e-3
+    total_ref = float(np.sqrt(sum(float(z[k]) ** 2 for k in z.files if k.startswith("gnorm/"))))
     sq = 0.0
     for k, p in m.named_parameters():
         gn = float(z[f"gnorm/{k}"])
@@ -77,11 +78,15 @@ def test_small_model_vs_reference_golden(golden_dir):
         if gn == 0.0:
             assert g is None or float(g.abs().max()) == 0.0, k
             continue
+        sq += float(g.double().pow(2).sum())
+        if gn < 1e-6 * total_ref:
+            # mathematically zero gradient (attn.k.bias: a per-row constant shift of the scores leaves softmax unchanged);
+            # the reference holds fp32 rounding noise there, so only the magnitude is comparable
+            assert float(g.double().norm()) <= 1e-4 * total_ref, k
+            continue
         ref = torch.from_numpy(z[f"grad/{k}"])
         mine = g.cpu() if g.numel() <= 8192 else g.cpu().flatten()[::7]
         assert rel(mine.reshape(ref.shape), ref) <= 5e-2, (k, rel(mine.reshape(ref.shape), ref))
-        sq += float(g.double().pow(2).sum())
-    total_ref = float(np.sqrt(sum(float(z[k]) ** 2 for k in z.files if k.startswith("gnorm/"))))
     assert abs(sq ** 0.5 - total_ref) <= 1e-2 * total_ref
 
 
@@ -118,8 +123,18 @@ def test_mid_model_vs_oracle_seeded():
     assert torch.equal(mask.cpu(), mask_r) and torch.equal(m._ids_restore.cpu(), ids_r)
     assert abs(float(loss) - float(loss_r)) <= 1e-3 * float(loss_r)
     assert rel(pred, pred_r) <= 1e-2
-    worst = max((rel(p.grad, grads_r[k]), k) for k, p in m.named_parameters() if float(grads_r[k].abs().max()) > 0)
+    total = float(O.grad_norm(grads_r.values()))
+    errs = {}
+    for k, p in m.named_parameters():
+        gr = grads_r[k]
+        if float(gr.norm()) < 1e-6 * total:          # exactly-zero (unused) or mathematically-zero (attn.k.bias) gradients
+            assert p.grad is None or float(p.grad.double().norm()) <= 1e-4 * total, k
+        else:
+            errs[k] = rel(p.grad, gr)
+    worst = max((v, k) for k, v in errs.items())
     assert worst[0] <= 5e-2, worst
+    print("mid model: loss rel %.2e pred rel %.2e worst grad rel %.2e (%s) median %.2e" % (
+        abs(float(loss) - float(loss_r)) / float(loss_r), rel(pred, pred_r), worst[0], worst[1], sorted(errs.values())[len(errs) // 2]))
 
 
 def test_train_step_matches_oracle_adamw():
