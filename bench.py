@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--clip-grad", type=float, default=None)
+    ap.add_argument("--force-reducer", action="store_true", help="single rank: still create the RCCL group and run the reducer")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -72,8 +73,10 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_reducer
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     from octcubem_amd import models_mae, misc, ops, optim as foptim
@@ -88,7 +91,7 @@ def main():
     torch.manual_seed(0)                                   # identical initial weights on every rank
     model = models_mae.octcube_vit_large_3dmae().to(dev)
     model.train()
-    reducer = FlatGradReducer(model) if world > 1 else None
+    reducer = FlatGradReducer(model, force=args.force_reducer) if use_dist else None
     model.prepare()
     if reducer is not None:
         reducer.broadcast_parameters(0)
@@ -109,7 +112,7 @@ def main():
         return last
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -125,7 +128,7 @@ def main():
     dt = time.perf_counter() - t0
     kt = ops.KTIMER.summary() if ops.KTIMER is not None else {}
     ops.KTIMER = None
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -166,7 +169,7 @@ def main():
             except Exception as e:  # the GPU number must survive a host that cannot fit the oracle
                 out["cpu_baseline"] = {"value": None, "unit": "volumes/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

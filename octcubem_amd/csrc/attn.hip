@@ -16,6 +16,8 @@
 // keeps the KEY on the lane and walks query tiles, so dK^T/dV^T accumulate in registers.
 // K/V (or Q/dO) tiles are 64 rows, register-staged, double-buffered in LDS with one barrier per tile; the
 // XOR swizzle makes both the ds_read_b128 row reads and the transposed reads bank-conflict-free.
+#include <type_traits>
+
 #include "common.hpp"
 #include "../../include/octmae.h"
 
@@ -87,11 +89,20 @@ __device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int s) {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// The attention kernels are bound by VALU issue (softmax), not by the MFMA pipe (rocprofv3: per-wave
+// SQ_ACTIVE_INST_VALU x 4 resident waves ~ 100 % of the SIMD), so the element-wise work is written on
+// register PAIRS: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process two scores per issue slot.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// log2-domain slack before the running max is updated (deferred rescale): P stays <= 2^8, exact in fp32 / bf16 range
+constexpr float RESCALE_SLACK = 8.0f;
+
 // =====================================================================================================
 // forward
 // =====================================================================================================
 template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+__global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                           float* __restrict__ lse, int N, int H, float scale) {
   constexpr int KS = HD / 16;   // k-steps over the head dimension
   constexpr int DB = HD / 32;   // 32-wide blocks of the head dimension
@@ -137,7 +148,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   }
   __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
+  // one 64-key tile; TAIL (last tile only) masks keys >= N.  m_run is tracked in RAW score units and the softmax scale
+  // is folded into the exp2 argument: p = exp2(s * sc2 - m * sc2) is one FMA + one v_exp_f32 per score.
+  auto tile = [&](int t, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
     const char* cK = (smem + (t & 1) * T::BYTES);
     const char* cV = (smem + (2 + (t & 1)) * T::BYTES);
     f32x16 sacc[2];
@@ -148,39 +162,50 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
       for (int s = 0; s < KS; ++s) sacc[kb] = mfma32(T::row_frag(cK, kb * 32, s, lane), qf[s], sacc[kb]);
     }
-    // scores in the log2 domain; mask the key tail of the last tile
-    const bool tail = (t == ntiles - 1) && (N & 63);
+    if (TAIL) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int key = t * 64 + kb * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+          if (key >= N) sacc[kb][g] = -INFINITY;
+        }
+    }
     float m_loc = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        float v = sacc[kb][g] * sc2;
-        if (tail) {
-          const int key = t * 64 + kb * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-          if (key >= N) v = -INFINITY;
-        }
-        sacc[kb][g] = v;
-        m_loc = fmaxf(m_loc, v);
-      }
+      for (int g = 0; g < 16; ++g) m_loc = fmaxf(m_loc, sacc[kb][g]);
     m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 32, 64));
-    const float m_new = fmaxf(m_run, m_loc);
-    const float alpha = fast_exp2(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
+    // Deferred rescale: the running max only moves when some row of the wave exceeds it by more than the slack, so after
+    // the first tiles the O / l rescale (and its exp) are skipped altogether.  Decision BEFORE this tile's P is formed:
+    // everything accumulated so far is at the old max and is scaled exactly once (wave-uniform branch).
+    if (!__all((m_loc - m_run) * sc2 <= RESCALE_SLACK)) {
+      const float m_new = fmaxf(m_run, m_loc);
+      const float alpha = fast_exp2((m_run - m_new) * sc2);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) oacc[d][g] *= alpha;
+    }
+    const float mneg = -m_run * sc2;
+    const f32x2 scv = {sc2, sc2}, mv = {mneg, mneg};
+    f32x2 ps = {0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const float p = fast_exp2(sacc[kb][g] - m_new);
-        sacc[kb][g] = p;
-        psum += p;
+      for (int g = 0; g < 16; g += 2) {
+        f32x2 v = {sacc[kb][g], sacc[kb][g + 1]};
+        v = pk_fma(v, scv, mv);
+        v[0] = fast_exp2(v[0]);
+        v[1] = fast_exp2(v[1]);
+        sacc[kb][g] = v[0];
+        sacc[kb][g + 1] = v[1];
+        ps += v;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-      for (int g = 0; g < 16; ++g) oacc[d][g] *= alpha;
+    l_run += ps[0] + ps[1];
     // O^T += V^T P^T
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -190,16 +215,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
         for (int d = 0; d < DB; ++d) oacc[d] = mfma32(T::tr_frag(cV, kb * 32, s, d * 32, lane), pf, oacc[d]);
       }
-    if (t + 1 < ntiles) {
-      sk.commit((smem + ((t + 1) & 1) * T::BYTES), tid);
-      sv.commit((smem + (2 + ((t + 1) & 1)) * T::BYTES), tid);
-      if (t + 2 < ntiles) {
-        sk.issue(kb_, rs, (t + 2) * 64, N, tid);
-        sv.issue(vb_, rs, (t + 2) * 64, N, tid);
-      }
+  };
+
+  for (int t = 0; t + 1 < ntiles; ++t) {
+    tile(t, std::false_type{});
+    sk.commit((smem + ((t + 1) & 1) * T::BYTES), tid);
+    sv.commit((smem + (2 + ((t + 1) & 1)) * T::BYTES), tid);
+    if (t + 2 < ntiles) {
+      sk.issue(kb_, rs, (t + 2) * 64, N, tid);
+      sv.issue(vb_, rs, (t + 2) * 64, N, tid);
     }
     __syncthreads();
   }
+  tile(ntiles - 1, std::true_type{});   // last tile: the only one that can hold keys >= N
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
@@ -213,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                    pack2bf(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv)};
         *reinterpret_cast<u32x2*>(orow + d * 32 + 8 * g + 4 * h) = w;
       }
-    if (h == 0) lse[((size_t)b * H + head) * N + qrow] = (m_run + __builtin_amdgcn_logf(l_tot)) * LN2;
+    if (h == 0) lse[((size_t)b * H + head) * N + qrow] = (m_run * sc2 + __builtin_amdgcn_logf(l_tot)) * LN2;
   }
 }
 
@@ -251,7 +279,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 //   dQ^T[d][query] += K^T[d][key] dS^T[key][query]
 // =====================================================================================================
 template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              bf16_t* __restrict__ dqkv, int N, int H, float scale) {
   constexpr int KS = HD / 16, DB = HD / 32;
@@ -305,27 +333,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   }
   __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
+  auto tile = [&](int t, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
     const char* cK = (smem + (t & 1) * T::BYTES);
     const char* cV = (smem + (2 + (t & 1)) * T::BYTES);
-    const bool tail = (t == ntiles - 1) && (N & 63);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 sa, dp;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) { sa[g] = 0.f; dp[g] = 0.f; }
+      for (int g = 0; g < 16; ++g) { sa[g] = 0.f; dp[g] = -dlt; }     // row constant -delta as the initial accumulator
 #pragma unroll
       for (int s = 0; s < KS; ++s) sa = mfma32(T::row_frag(cK, kb * 32, s, lane), qf[s], sa);
 #pragma unroll
       for (int s = 0; s < KS; ++s) dp = mfma32(T::row_frag(cV, kb * 32, s, lane), dof[s], dp);
+      const f32x2 scv = {sc2, sc2}, lv = {-lse2, -lse2};
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        float p = fast_exp2(fmaf(sa[g], sc2, -lse2));
-        if (tail) {
-          const int key = t * 64 + kb * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-          if (key >= N) p = 0.f;
+      for (int g = 0; g < 16; g += 2) {
+        f32x2 v = {sa[g], sa[g + 1]};
+        v = pk_fma(v, scv, lv);
+        v[0] = fast_exp2(v[0]);
+        v[1] = fast_exp2(v[1]);
+        if (TAIL) {
+          const int key = t * 64 + kb * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;   // g even: key(g+1) = key(g) + 1
+          if (key >= N) v[0] = 0.f;
+          if (key + 1 >= N) v[1] = 0.f;
         }
-        sa[g] = p * (dp[g] - dlt) * scale;
+        const f32x2 d2 = {dp[g], dp[g + 1]};
+        v *= d2;                                                       // dS / scale; scale is applied to dQ once
+        sa[g] = v[0];
+        sa[g + 1] = v[1];
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -334,16 +370,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         for (int d = 0; d < DB; ++d) dq[d] = mfma32(T::tr_frag(cK, kb * 32, s, d * 32, lane), dsf, dq[d]);
       }
     }
-    if (t + 1 < ntiles) {
-      sk.commit((smem + ((t + 1) & 1) * T::BYTES), tid);
-      sv.commit((smem + (2 + ((t + 1) & 1)) * T::BYTES), tid);
-      if (t + 2 < ntiles) {
-        sk.issue(kb_, rs, (t + 2) * 64, N, tid);
-        sv.issue(vb_, rs, (t + 2) * 64, N, tid);
-      }
+  };
+  for (int t = 0; t + 1 < ntiles; ++t) {
+    tile(t, std::false_type{});
+    sk.commit((smem + ((t + 1) & 1) * T::BYTES), tid);
+    sv.commit((smem + (2 + ((t + 1) & 1)) * T::BYTES), tid);
+    if (t + 2 < ntiles) {
+      sk.issue(kb_, rs, (t + 2) * 64, N, tid);
+      sv.issue(vb_, rs, (t + 2) * 64, N, tid);
     }
     __syncthreads();
   }
+  tile(ntiles - 1, std::true_type{});   // last tile: the only one that can hold keys >= N
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) dq[d][g] *= scale;
   if (qrow < N) {
     bf16_t* drow = dqkv + ((size_t)b * N + qrow) * rs + (size_t)head * HD;
 #pragma unroll
@@ -363,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 //   dP = dO V^T - delta ; dS = P dP scale ; dK^T[d][key] += Q^T[d][query] dS[query][key]
 // =====================================================================================================
 template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               bf16_t* __restrict__ dqkv, int N, int H, float scale) {
   constexpr int KS = HD / 16, DB = HD / 32;
@@ -454,10 +496,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 #pragma unroll
       for (int s = 0; s < KS; ++s) dp = mfma32(T::row_frag(cO, qb32 * 32, s, lane), vf[s], dp);
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const float p = fast_exp2(sa[g] * sc2);
-        sa[g] = p;
-        dp[g] = p * dp[g] * scale;
+      for (int g = 0; g < 16; g += 2) {
+        f32x2 v = {sa[g], sa[g + 1]};
+        v *= f32x2{sc2, sc2};
+        v[0] = fast_exp2(v[0]);
+        v[1] = fast_exp2(v[1]);
+        f32x2 d2 = {dp[g], dp[g + 1]};
+        d2 *= v;                                                       // dS / scale; scale is applied to dK once
+        sa[g] = v[0]; sa[g + 1] = v[1];
+        dp[g] = d2[0]; dp[g + 1] = d2[1];
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -482,6 +529,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     }
     __syncthreads();
   }
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) dk[d][g] *= scale;
   if (krow < N) {
     bf16_t* drow = dqkv + ((size_t)b * N + krow) * rs + (size_t)head * HD;
 #pragma unroll

@@ -46,27 +46,39 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// ---- exact-erf GELU (timm Mlp act_layer=nn.GELU), Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7) --
-__device__ __forceinline__ float erf_as(float x) {
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
-  float p = 1.061405429f;
-  p = fmaf(p, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __expf(-ax * ax);
-  const float r = 1.0f - p * t * e;
-  return copysignf(r, x);
+// ---- GELU (timm Mlp act_layer=nn.GELU, exact-erf form x * Phi(x)) ---------------------------------------------
+// Phi(x) = 0.5 + u * P(u^2), u = clamp(x, +-4.5): odd minimax polynomial of degree 15, |Phi error| <= 7.8e-5 (fp32 Horner),
+// i.e. 50x below the bf16 resolution of the stored activation.  No transcendental: the epilogue of the fc1 GEMM is VALU
+// work that the MFMA pipe cannot hide at one workgroup per CU (the A&S erf form with v_rcp + v_exp cost 2.4x more).
+// The backward uses a separate fit of gelu'(x) = Phi(x) + x phi(x) = 0.5 + u * Q(u^2), u = clamp(x, +-5), |error| <= 4.4e-4.
+__device__ __forceinline__ float gelu_phi(float x) {
+  const float u = __builtin_amdgcn_fmed3f(x, -4.5f, 4.5f);
+  const float t = u * u;
+  float p = -7.715688019e-10f;
+  p = fmaf(p, t, 7.192630176e-08f);
+  p = fmaf(p, t, -2.879689972e-06f);
+  p = fmaf(p, t, 6.548595686e-05f);
+  p = fmaf(p, t, -9.478268993e-04f);
+  p = fmaf(p, t, 9.327514321e-03f);
+  p = fmaf(p, t, -6.568239007e-02f);
+  p = fmaf(p, t, 3.986432605e-01f);
+  return fmaf(u, p, 0.5f);
 }
-__device__ __forceinline__ float gelu_f(float x) {
-  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f));
-}
-// d/dx gelu(x) = Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_f(float x) { return x * gelu_phi(x); }
 __device__ __forceinline__ float dgelu_f(float x) {
-  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-  return fmaf(x, pdf, cdf);
+  const float u = __builtin_amdgcn_fmed3f(x, -5.0f, 5.0f);
+  const float t = u * u;
+  float q = -8.945184002e-12f;
+  q = fmaf(q, t, 1.221804868e-09f);
+  q = fmaf(q, t, -7.286091231e-08f);
+  q = fmaf(q, t, 2.499930865e-06f);
+  q = fmaf(q, t, -5.482182127e-05f);
+  q = fmaf(q, t, 8.080908045e-04f);
+  q = fmaf(q, t, -8.191250186e-03f);
+  q = fmaf(q, t, 5.702680522e-02f);
+  q = fmaf(q, t, -2.631234724e-01f);
+  q = fmaf(q, t, 7.970332990e-01f);
+  return fmaf(u, q, 0.5f);
 }
 
 // ---- MFMA wrappers ---------------------------------------------------------------------------

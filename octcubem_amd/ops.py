@@ -125,9 +125,12 @@ def colsum_accum(x2d: torch.Tensor, out: torch.Tensor):
 _GEMM_KIND = {(0, 0): "gemm_fwd", (1, 0): "gemm_dgrad", (1, 1): "gemm_wgrad"}
 
 
+FORCE_SMALL_TILE = False    # tests: route every GEMM through the 128-tile register-staged kernel
+
+
 def _gemm(A, B, C, NA, NB, K, lda, ldb, ldc, a_ks, b_ks, epi, C2=None, bias=None, aux=None, ldaux=0, splitk=1):
-    args = (A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(C2), _p(bias), _p(aux), NA, NB, K, lda, ldb, ldc, ldaux, a_ks, b_ks, epi,
-            splitk, _stream())
+    args = (A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(C2), _p(bias), _p(aux), NA, NB, K, lda, ldb, ldc, ldaux, a_ks, b_ks,
+            epi | (0x100 if FORCE_SMALL_TILE else 0), splitk, _stream())
     if KTIMER is None:
         call("octmae_gemm_bf16", *args)
     else:
@@ -175,9 +178,10 @@ def linear_dgrad(dy: torch.Tensor, w: torch.Tensor, pre: Optional[torch.Tensor] 
     return dx
 
 
-def _splitk_for(n_out_tiles: int, ktiles: int) -> int:
-    # fill >= 2 workgroups per CU (512 on MI355X) but keep >= 8 k-tiles (512 rows) per slice
-    s = max(1, (512 + n_out_tiles - 1) // n_out_tiles)
+def _splitk_for(n_out_tiles: int, ktiles: int, target_blocks: int) -> int:
+    # as many k-slices as keep tiles x slices within ONE round of workgroups over the chip (a second, partly filled
+    # round costs more than the slightly lower fill), and >= 8 k-tiles (512 token rows) per slice
+    s = max(1, target_blocks // n_out_tiles)
     return max(1, min(s, ktiles // 8 if ktiles >= 8 else 1))
 
 
@@ -185,9 +189,11 @@ def linear_wgrad_accum(dy: torch.Tensor, x: torch.Tensor, gw: torch.Tensor):
     """gw[N,K] (f32) += dy[M,N].T @ x[M,K]."""
     M, N = dy.shape
     K = x.shape[1]
-    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    big = N >= 256 and K >= 256 and not FORCE_SMALL_TILE          # mirrors the tile choice in octmae_gemm_bf16
+    t = 256 if big else 128
+    tiles = ((N + t - 1) // t) * ((K + t - 1) // t)
     ktiles = (M + 63) // 64
-    _gemm(dy, x, gw, N, K, M, dy.stride(0), x.stride(0), gw.stride(0), 1, 1, EPI_ACCUM, splitk=_splitk_for(tiles, ktiles))
+    _gemm(dy, x, gw, N, K, M, dy.stride(0), x.stride(0), gw.stride(0), 1, 1, EPI_ACCUM, splitk=_splitk_for(tiles, ktiles, 256 if big else 1024))
 
 
 def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float):

@@ -28,12 +28,15 @@ from . import ops
 
 
 class FlatGradReducer:
-    def __init__(self, model, n_chunks: int = 8, process_group=None, average: bool = True):
+    def __init__(self, model, n_chunks: int = 8, process_group=None, average: bool = True, overlap: bool = True,
+                 force: bool = False):
         self.model = model
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
         self.n_chunks = n_chunks
+        self.overlap = overlap      # False: exchange everything in finish() (needed when a parameter is used twice per backward)
+        self.force = force          # run the exchange even with a single rank (exercises the RCCL path on one GPU)
         self._arena = None
         self._sync = True
         self._pending: List = []
@@ -79,15 +82,15 @@ class FlatGradReducer:
     def begin_backward(self, sync: bool = True):
         """Call before loss.backward().  sync=False (accumulation micro-step): no exchange."""
         self._layout()
-        self._sync = sync and self.world > 1
+        self._sync = sync and (self.world > 1 or self.force)
         self._remaining = list(self.remaining_init)
         self._seen = set()
         self._launched = [False] * len(self.bounds)
         self._pending = []
-        ops.set_grad_ready_callback(self._on_ready if self._sync else None)
+        ops.set_grad_ready_callback(self._on_ready if (self._sync and self.overlap) else None)
 
     def _autograd_hook(self, p):
-        if self._sync:
+        if self._sync and self.overlap:
             self._on_ready([p])
 
     def _on_ready(self, params):
@@ -136,5 +139,5 @@ class FlatGradReducer:
     def broadcast_parameters(self, src: int = 0):
         """DDP's constructor broadcast: make every rank start from rank `src`'s weights (one collective)."""
         self._layout()
-        if self.world > 1:
+        if self.world > 1 or self.force:
             dist.broadcast(self._arena.flat, src=src, group=self.group)

@@ -72,11 +72,21 @@ def test_probe_ds_read_tr_lane_map():
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-GEMM_SHAPES = [(128, 128, 64), (256, 384, 128), (200, 136, 72), (1281, 384, 128), (64, 64, 64), (5121, 192, 64), (130, 768, 512)]
+GEMM_SHAPES = [(128, 128, 64), (256, 384, 128), (200, 136, 72), (1281, 384, 128), (64, 64, 64), (5121, 192, 64), (130, 768, 512),
+               (600, 512, 256), (2000, 1024, 1024), (3000, 512, 256), (2562, 768, 512)]
+
+
+@pytest.fixture(params=["auto", "tile128"])
+def tile_variant(request):
+    """Every GEMM problem runs through the automatic choice (256-tile LDS-DMA kernel when it fits) and through the
+    128-tile register-staged kernel."""
+    ops.FORCE_SMALL_TILE = request.param == "tile128"
+    yield request.param
+    ops.FORCE_SMALL_TILE = False
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-def test_gemm_forward_epilogues(M, N, K):
+def test_gemm_forward_epilogues(M, N, K, tile_variant):
     g = torch.Generator().manual_seed(M * 7 + N)
     x = bf(torch.randn(M, K, generator=g)).to(DEV)
     w = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
@@ -100,7 +110,7 @@ def test_gemm_forward_epilogues(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-def test_gemm_dgrad_and_wgrad(M, N, K):
+def test_gemm_dgrad_and_wgrad(M, N, K, tile_variant):
     g = torch.Generator().manual_seed(M + N * 3)
     x = bf(torch.randn(M, K, generator=g)).to(DEV)
     w = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
