@@ -42,12 +42,15 @@ int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2, const floa
  * nn.LayerNorm(eps=1e-6): models_mae_joint_res_flash_attn.py:799, video_vit.py:161,172,181-184, :489, :592.
  * fwd: y bf16 = (x - mean) * rstd * gamma + beta; saves mean, rstd (fp32 [M]).
  * bwd: dx f32 = (dres ? dres : 0) + LN'(dy); optional bf16 copy of dx; dgamma/dbeta/dxsum (column sums of
- *      dx = bias gradient of the preceding Linear) are ACCUMULATED (+=) when non-NULL.  D % 4 == 0, D <= 2048. */
+ *      dx = bias gradient of the preceding Linear) are ACCUMULATED (+=) when non-NULL (two-stage, deterministic, through the
+ *      caller-provided workspace partial_ws).  D % 4 == 0, D <= 2048. */
 int octmae_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean, float* rstd,
                          int M, int D, float eps, void* stream);
 int octmae_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* gamma,
-                         const float* dres, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* dxsum, int M,
-                         int D, void* stream);
+                         const float* dres, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* dxsum,
+                         float* partial_ws, int M, int D, void* stream);
+/* number of floats `partial_ws` must hold for (M, D) */
+int octmae_layernorm_bwd_ws_floats(int M, int D);
 
 /* ---- attention -----------------------------------------------------------------------------------
  * softmax(q k^T * scale) v, non-causal, no dropout: video_vit.py:130-134 (flash path: flash_attn MHA,

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboctmae.so")
+LIB_PATH = os.environ.get("OCTMAE_LIB", os.path.join(_HERE, "liboctmae.so"))   # OCTMAE_LIB: A/B a variant build
 
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
@@ -18,7 +18,8 @@ SIGNATURES = {
     "octmae_abi_version": [],
     "octmae_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "octmae_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
-    "octmae_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "octmae_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "octmae_layernorm_bwd_ws_floats": [_i, _i],
     "octmae_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "octmae_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "octmae_attn_bwd_delta": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],

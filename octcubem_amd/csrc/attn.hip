@@ -23,6 +23,15 @@
 
 namespace octmae {
 
+#ifndef ATT_OCC_FWD32
+#define ATT_OCC_FWD32 3
+#endif
+#ifndef ATT_OCC_DQ32
+#define ATT_OCC_DQ32 3
+#endif
+#ifndef ATT_OCC_DKV32
+#define ATT_OCC_DKV32 3
+#endif
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -89,20 +98,29 @@ __device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int s) {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// The attention kernels are bound by VALU issue (softmax), not by the MFMA pipe (rocprofv3: per-wave
-// SQ_ACTIVE_INST_VALU x 4 resident waves ~ 100 % of the SIMD), so the element-wise work is written on
-// register PAIRS: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process two scores per issue slot.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-
-// log2-domain slack before the running max is updated (deferred rescale): P stays <= 2^8, exact in fp32 / bf16 range
+// The attention kernels are bound by VALU issue (softmax), not by the MFMA pipe: rocprofv3 shows per-wave
+// SQ_ACTIVE_INST_VALU x resident waves ~ 100 % of the SIMD, and tools/ubench/valu_rate.hip prices the opcodes at
+// 2 cycles (v_fma/v_add/v_max), 4 (v_max3, v_cvt_pk_bf16_f32, every v_pk_*_f32) and 8 (v_exp_f32) per wave-instruction.
+// So the per-score work is cut to  exp + cvt (+ max):
+//   * Q (forward, dQ) / K (dK/dV) fragments are pre-multiplied by scale*log2(e) once per workgroup and the S accumulator
+//     starts at the row constant (-running max, or -LSE*log2e in backward): the MFMA result IS the exp2 argument;
+//   * head_dim 32 (where the MFMA pipe has slack) gets its softmax row sums from one extra MFMA against an all-ones
+//     operand instead of 32 v_add per tile;
+//   * the running max moves only when a row exceeds it by more than RESCALE_SLACK (log2 units), P <= 2^8.
 constexpr float RESCALE_SLACK = 8.0f;
+
+__device__ __forceinline__ bf16x8 scale_frag(u32x4 v, float s) {
+  u32x4 w;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) w[e] = pack2bf(bflo(v[e]) * s, bfhi(v[e]) * s);
+  return __builtin_bit_cast(bf16x8, w);
+}
 
 // =====================================================================================================
 // forward
 // =====================================================================================================
 template <int HD>
-__global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+__global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 2)) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                           float* __restrict__ lse, int N, int H, float scale) {
   constexpr int KS = HD / 16;   // k-steps over the head dimension
   constexpr int DB = HD / 32;   // 32-wide blocks of the head dimension
@@ -120,116 +138,136 @@ __global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_fwd_kernel(const
   const int q0 = blockIdx.x * 128 + wid * 32;
   const int qrow = q0 + r;
 
-  bf16x8 qf[KS];
+  constexpr bool ONES_SUM = (HD == 32);
+  const float sc2 = scale * LOG2E;
+  bf16x8 qf[KS];   // Q^T fragments, pre-scaled by scale*log2(e): S accumulates directly in the exp2 domain
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     u32x4 v = {0u, 0u, 0u, 0u};
     if (qrow < N) v = *reinterpret_cast<const u32x4*>(qb + (size_t)qrow * rs + 16 * s + 8 * h);
-    qf[s] = __builtin_bit_cast(bf16x8, v);
+    qf[s] = scale_frag(v, sc2);
   }
+  const u32x4 ones_w = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_w);
 
-  f32x16 oacc[DB];
+  f32x16 oacc[DB], lacc;
 #pragma unroll
   for (int d = 0; d < DB; ++d)
 #pragma unroll
     for (int g = 0; g < 16; ++g) oacc[d][g] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-  const float sc2 = scale * LOG2E;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) lacc[g] = 0.f;
+  float m_s = 0.f, l_run = 0.f;   // running max (scaled log2 domain) and, for head_dim 64, the per-lane partial row sum
 
+  // Software pipeline across key tiles: S_{t+1} = K_{t+1} Q^T is issued (MFMA pipe) right after the rescale decision of
+  // tile t and runs under tile t's exp / convert (VALU); P_t V_t follows.  K is therefore staged one tile ahead of V:
+  //   iteration t reads Kbuf[(t+1)&1] (K_{t+1}) and Vbuf[t&1] (V_t); at its end V_{t+1} -> Vbuf[(t+1)&1], K_{t+2} -> Kbuf[t&1].
   const int ntiles = (N + 63) / 64;
   TileStage<HD> sk, sv;
+  char* const Kbuf = smem;
+  char* const Vbuf = smem + 2 * T::BYTES;
   sk.issue(kb_, rs, 0, N, tid);
   sv.issue(vb_, rs, 0, N, tid);
-  sk.commit(smem, tid);
-  sv.commit((smem + 2 * T::BYTES), tid);
+  sk.commit(Kbuf, tid);
+  sv.commit(Vbuf, tid);
   if (ntiles > 1) {
     sk.issue(kb_, rs, 64, N, tid);
+    sk.commit(Kbuf + T::BYTES, tid);
     sv.issue(vb_, rs, 64, N, tid);
+    if (ntiles > 2) sk.issue(kb_, rs, 128, N, tid);
   }
   __syncthreads();
 
-  // one 64-key tile; TAIL (last tile only) masks keys >= N.  m_run is tracked in RAW score units and the softmax scale
-  // is folded into the exp2 argument: p = exp2(s * sc2 - m * sc2) is one FMA + one v_exp_f32 per score.
-  auto tile = [&](int t, auto tail_tag) {
-    constexpr bool TAIL = decltype(tail_tag)::value;
-    const char* cK = (smem + (t & 1) * T::BYTES);
-    const char* cV = (smem + (2 + (t & 1)) * T::BYTES);
-    f32x16 sacc[2];
+  auto qk = [&](const char* cK, f32x16 (&sa)[2]) {
+    const float neg_m = -m_s;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int g = 0; g < 16; ++g) sacc[kb][g] = 0.f;
+      for (int g = 0; g < 16; ++g) sa[kb][g] = neg_m;          // row constant as the initial accumulator
 #pragma unroll
-      for (int s = 0; s < KS; ++s) sacc[kb] = mfma32(T::row_frag(cK, kb * 32, s, lane), qf[s], sacc[kb]);
+      for (int s = 0; s < KS; ++s) sa[kb] = mfma32(T::row_frag(cK, kb * 32, s, lane), qf[s], sa[kb]);
     }
-    if (TAIL) {
+  };
+
+  // tile t: scur = S_t (already computed), snext <- S_{t+1}
+  auto step = [&](int t, f32x16 (&scur)[2], f32x16 (&snext)[2]) {
+    const bool last = (t + 1 == ntiles);
+    const char* cV = Vbuf + (t & 1) * T::BYTES;
+    if (last) {                                                  // only the last tile can hold keys >= N
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
           const int key = t * 64 + kb * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-          if (key >= N) sacc[kb][g] = -INFINITY;
+          if (key >= N) scur[kb][g] = -INFINITY;
         }
     }
-    float m_loc = -INFINITY;
+    // excess of this tile's scores over the running max (two chains for ILP)
+    float e0 = scur[0][0], e1 = scur[1][0];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int g = 0; g < 16; ++g) m_loc = fmaxf(m_loc, sacc[kb][g]);
-    m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 32, 64));
-    // Deferred rescale: the running max only moves when some row of the wave exceeds it by more than the slack, so after
-    // the first tiles the O / l rescale (and its exp) are skipped altogether.  Decision BEFORE this tile's P is formed:
-    // everything accumulated so far is at the old max and is scaled exactly once (wave-uniform branch).
-    if (!__all((m_loc - m_run) * sc2 <= RESCALE_SLACK)) {
-      const float m_new = fmaxf(m_run, m_loc);
-      const float alpha = fast_exp2((m_run - m_new) * sc2);
-      m_run = m_new;
+    for (int g = 1; g < 16; ++g) { e0 = fmaxf(e0, scur[0][g]); e1 = fmaxf(e1, scur[1][g]); }
+    float ex = fmaxf(e0, e1);
+    ex = fmaxf(ex, __shfl_xor(ex, 32, 64));
+    // Deferred rescale (wave-uniform, rare after the first tiles): decided BEFORE this tile's P is formed, so everything
+    // accumulated so far is at the old max and is scaled exactly once; the pending scores are shifted by the same amount.
+    if (t == 0 || !__all(ex <= RESCALE_SLACK)) {
+      const float d = (t == 0) ? ex : fmaxf(ex, 0.f);
+      const float alpha = fast_exp2(-d);
+      m_s += d;
       l_run *= alpha;
+      lacc[0] *= alpha;
 #pragma unroll
-      for (int d = 0; d < DB; ++d)
+      for (int dd = 0; dd < DB; ++dd)
 #pragma unroll
-        for (int g = 0; g < 16; ++g) oacc[d][g] *= alpha;
+        for (int g = 0; g < 16; ++g) oacc[dd][g] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) scur[kb][g] -= d;
     }
-    const float mneg = -m_run * sc2;
-    const f32x2 scv = {sc2, sc2}, mv = {mneg, mneg};
-    f32x2 ps = {0.f, 0.f};
+    if (!last) qk(Kbuf + ((t + 1) & 1) * T::BYTES, snext);      // MFMA pipe works on S_{t+1} under the exps below
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int g = 0; g < 16; g += 2) {
-        f32x2 v = {sacc[kb][g], sacc[kb][g + 1]};
-        v = pk_fma(v, scv, mv);
-        v[0] = fast_exp2(v[0]);
-        v[1] = fast_exp2(v[1]);
-        sacc[kb][g] = v[0];
-        sacc[kb][g + 1] = v[1];
-        ps += v;
+      for (int g = 0; g < 16; g += 4) {
+        const float p0 = fast_exp2(scur[kb][g]), p1 = fast_exp2(scur[kb][g + 1]);
+        const float p2 = fast_exp2(scur[kb][g + 2]), p3 = fast_exp2(scur[kb][g + 3]);
+        scur[kb][g] = p0; scur[kb][g + 1] = p1; scur[kb][g + 2] = p2; scur[kb][g + 3] = p3;
+        if (!ONES_SUM) { s0 += p0; s1 += p1; s2 += p2; s3 += p3; }
       }
-    l_run += ps[0] + ps[1];
-    // O^T += V^T P^T
+    if (!ONES_SUM) l_run += (s0 + s1) + (s2 + s3);
+    // O^T += V^T P^T   (and, head_dim 32, row sums += 1^T P^T on the MFMA pipe)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8 pf = acc_to_frag(sacc[kb], s);
+        const bf16x8 pf = acc_to_frag(scur[kb], s);
 #pragma unroll
         for (int d = 0; d < DB; ++d) oacc[d] = mfma32(T::tr_frag(cV, kb * 32, s, d * 32, lane), pf, oacc[d]);
+        if (ONES_SUM) lacc = mfma32(ones, pf, lacc);
       }
-  };
-
-  for (int t = 0; t + 1 < ntiles; ++t) {
-    tile(t, std::false_type{});
-    sk.commit((smem + ((t + 1) & 1) * T::BYTES), tid);
-    sv.commit((smem + (2 + ((t + 1) & 1)) * T::BYTES), tid);
-    if (t + 2 < ntiles) {
-      sk.issue(kb_, rs, (t + 2) * 64, N, tid);
-      sv.issue(vb_, rs, (t + 2) * 64, N, tid);
+    // staging for the tiles ahead
+    if (t + 1 < ntiles) {
+      sv.commit(Vbuf + ((t + 1) & 1) * T::BYTES, tid);
+      if (t + 2 < ntiles) {
+        sk.commit(Kbuf + (t & 1) * T::BYTES, tid);
+        sv.issue(vb_, rs, (t + 2) * 64, N, tid);
+        if (t + 3 < ntiles) sk.issue(kb_, rs, (t + 3) * 64, N, tid);
+      }
     }
     __syncthreads();
-  }
-  tile(ntiles - 1, std::true_type{});   // last tile: the only one that can hold keys >= N
+  };
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  f32x16 sA[2], sB[2];
+  qk(Kbuf, sA);
+  for (int t = 0; t < ntiles; t += 2) {
+    step(t, sA, sB);
+    if (t + 1 < ntiles) step(t + 1, sB, sA);
+  }
+
+  // every row of the ones-MFMA accumulator holds the full row sum (both lane halves); the VALU form is per half
+  const float l_tot = ONES_SUM ? lacc[0] : (l_run + __shfl_xor(l_run, 32, 64));
   const float inv = 1.0f / l_tot;
   if (qrow < N) {
     bf16_t* orow = o + ((size_t)b * N + qrow) * (size_t)(H * HD) + (size_t)head * HD;
@@ -241,7 +279,7 @@ __global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_fwd_kernel(const
                    pack2bf(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv)};
         *reinterpret_cast<u32x2*>(orow + d * 32 + 8 * g + 4 * h) = w;
       }
-    if (h == 0) lse[((size_t)b * H + head) * N + qrow] = (m_run * sc2 + __builtin_amdgcn_logf(l_tot)) * LN2;
+    if (h == 0) lse[((size_t)b * H + head) * N + qrow] = (m_s + __builtin_amdgcn_logf(l_tot)) * LN2;
   }
 }
 
@@ -279,7 +317,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 //   dQ^T[d][query] += K^T[d][key] dS^T[key][query]
 // =====================================================================================================
 template <int HD>
-__global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DQ32 : 2)) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              bf16_t* __restrict__ dqkv, int N, int H, float scale) {
   constexpr int KS = HD / 16, DB = HD / 32;
@@ -296,6 +334,7 @@ __global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_bwd_dq_kernel(co
   const bf16_t* vb_ = qb + (size_t)2 * H * HD;
   const int qrow = blockIdx.x * 128 + wid * 32 + r;
   const size_t ostride = (size_t)H * HD;
+  const float sc2 = scale * LOG2E;
 
   bf16x8 qf[KS], dof[KS];
 #pragma unroll
@@ -305,7 +344,7 @@ __global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_bwd_dq_kernel(co
       v = *reinterpret_cast<const u32x4*>(qb + (size_t)qrow * rs + 16 * s + 8 * h);
       w = *reinterpret_cast<const u32x4*>(dout + ((size_t)b * N + qrow) * ostride + (size_t)head * HD + 16 * s + 8 * h);
     }
-    qf[s] = __builtin_bit_cast(bf16x8, v);
+    qf[s] = scale_frag(v, sc2);                 // pre-scaled: S^T accumulates in the exp2 domain (used for S only)
     dof[s] = __builtin_bit_cast(bf16x8, w);
   }
   float lse2 = 0.f, dlt = 0.f;
@@ -313,7 +352,6 @@ __global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_bwd_dq_kernel(co
     lse2 = lse[((size_t)b * H + head) * N + qrow] * LOG2E;
     dlt = delta[((size_t)b * H + head) * N + qrow];
   }
-  const float sc2 = scale * LOG2E;
 
   f32x16 dq[DB];
 #pragma unroll
@@ -341,27 +379,19 @@ __global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_bwd_dq_kernel(co
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 sa, dp;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) { sa[g] = 0.f; dp[g] = -dlt; }     // row constant -delta as the initial accumulator
+      for (int g = 0; g < 16; ++g) { sa[g] = -lse2; dp[g] = -dlt; }   // row constants as the initial accumulators
 #pragma unroll
       for (int s = 0; s < KS; ++s) sa = mfma32(T::row_frag(cK, kb * 32, s, lane), qf[s], sa);
 #pragma unroll
       for (int s = 0; s < KS; ++s) dp = mfma32(T::row_frag(cV, kb * 32, s, lane), dof[s], dp);
-      const f32x2 scv = {sc2, sc2}, lv = {-lse2, -lse2};
 #pragma unroll
-      for (int g = 0; g < 16; g += 2) {
-        f32x2 v = {sa[g], sa[g + 1]};
-        v = pk_fma(v, scv, lv);
-        v[0] = fast_exp2(v[0]);
-        v[1] = fast_exp2(v[1]);
+      for (int g = 0; g < 16; ++g) {
+        float p = fast_exp2(sa[g]);
         if (TAIL) {
-          const int key = t * 64 + kb * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;   // g even: key(g+1) = key(g) + 1
-          if (key >= N) v[0] = 0.f;
-          if (key + 1 >= N) v[1] = 0.f;
+          const int key = t * 64 + kb * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+          if (key >= N) p = 0.f;
         }
-        const f32x2 d2 = {dp[g], dp[g + 1]};
-        v *= d2;                                                       // dS / scale; scale is applied to dQ once
-        sa[g] = v[0];
-        sa[g + 1] = v[1];
+        sa[g] = p * dp[g];                                             // dS / scale; scale is applied to dQ once
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -400,19 +430,19 @@ __global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_bwd_dq_kernel(co
 
 // =====================================================================================================
 // backward dK/dV: keys on the lane (32 per wave, 128 per block), walks 64-query tiles of Q and dO
-//   S = Q K^T - lse/scale (row constant as the initial accumulator) ; P = exp2(S*scale*log2e)
+//   S' = Q (K*scale*log2e)^T - lse*log2e (row constant as the initial accumulator) ; P = exp2(S')
 //   dV^T[d][key] += dO^T[d][query] P[query][key]
 //   dP = dO V^T - delta ; dS = P dP scale ; dK^T[d][key] += Q^T[d][query] dS[query][key]
 // =====================================================================================================
 template <int HD>
-__global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DKV32 : 2)) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               bf16_t* __restrict__ dqkv, int N, int H, float scale) {
   constexpr int KS = HD / 16, DB = HD / 32;
   using T = Tile<HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // LDS: Q0 Q1 O0 O1
-  float* ldsC = reinterpret_cast<float*>(smem + 4 * T::BYTES);  // [2 buffers][2: -lse/scale, -delta][64]
+  float* ldsC = reinterpret_cast<float*>(smem + 4 * T::BYTES);  // [2 buffers][2: -lse*log2e, -delta][64]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -426,6 +456,7 @@ __global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(c
   const float* lse_b = lse + ((size_t)b * H + head) * N;
   const float* dlt_b = delta + ((size_t)b * H + head) * N;
   const int krow = blockIdx.x * 128 + wid * 32 + r;
+  const float sc2 = scale * LOG2E;
 
   bf16x8 kf[KS], vf[KS];
 #pragma unroll
@@ -435,11 +466,9 @@ __global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(c
       v = *reinterpret_cast<const u32x4*>(kb_ + (size_t)krow * rs + 16 * s + 8 * h);
       w = *reinterpret_cast<const u32x4*>(vb_ + (size_t)krow * rs + 16 * s + 8 * h);
     }
-    kf[s] = __builtin_bit_cast(bf16x8, v);
+    kf[s] = scale_frag(v, sc2);                 // pre-scaled: S accumulates in the exp2 domain (used for S only)
     vf[s] = __builtin_bit_cast(bf16x8, w);
   }
-  const float sc2 = scale * LOG2E;
-  const float inv_scale = 1.0f / scale;
 
   f32x16 dk[DB], dv[DB];
 #pragma unroll
@@ -453,7 +482,7 @@ __global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(c
   auto issue_consts = [&](int row0) {
     if (tid < 64) {
       const int q = row0 + tid;
-      c_lse = (q < N) ? -lse_b[q] * inv_scale : 0.f;
+      c_lse = (q < N) ? -lse_b[q] * LOG2E : 0.f;
       c_dlt = (q < N) ? -dlt_b[q] : 0.f;
     }
   };
@@ -496,15 +525,10 @@ __global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(c
 #pragma unroll
       for (int s = 0; s < KS; ++s) dp = mfma32(T::row_frag(cO, qb32 * 32, s, lane), vf[s], dp);
 #pragma unroll
-      for (int g = 0; g < 16; g += 2) {
-        f32x2 v = {sa[g], sa[g + 1]};
-        v *= f32x2{sc2, sc2};
-        v[0] = fast_exp2(v[0]);
-        v[1] = fast_exp2(v[1]);
-        f32x2 d2 = {dp[g], dp[g + 1]};
-        d2 *= v;                                                       // dS / scale; scale is applied to dK once
-        sa[g] = v[0]; sa[g + 1] = v[1];
-        dp[g] = d2[0]; dp[g + 1] = d2[1];
+      for (int g = 0; g < 16; ++g) {
+        const float p = fast_exp2(sa[g]);
+        sa[g] = p;
+        dp[g] = p * dp[g];                                             // dS / scale; scale is applied to dK once
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {

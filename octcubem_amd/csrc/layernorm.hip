@@ -5,8 +5,8 @@
 // loads), statistics by wave64 butterfly shuffles, bf16 output packed 8 bytes per chunk.
 //   fwd bytes/element: 4 (x) read + 2 (y) write
 //   bwd bytes/element: 2 (dy) + 4 (x) read, 4 (dx) [+2 (dx bf16)] write; dgamma/dbeta/column sums are
-//   accumulated per lane across the rows a wave walks, reduced over the block in LDS and added with
-//   one fp32 atomic per column per block.
+//   accumulated per lane across the rows a wave walks, reduced over the block in LDS, written as per-block
+//   partials to a caller-provided workspace and folded by a second small kernel (deterministic, no atomics).
 #include "common.hpp"
 #include "../../include/octmae.h"
 
@@ -85,8 +85,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      float* __restrict__ dx, bf16_t* __restrict__ dxb,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     float* __restrict__ dxsum, int M, int D) {
+                                                     float* __restrict__ partial, bool want_dxsum, int M, int D) {
   __shared__ float red[3][4][64 * 4 + 4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wave = blockIdx.x * 4 + w;
@@ -101,26 +100,52 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 4; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; as[c][e] = 0.f; }
   }
+  // Software-pipelined over rows: the loads of the NEXT row are issued before the current row is reduced, so every
+  // wave keeps two rows (12-20 KB) in flight -- with one row per wave the kernel sat at ~35 % of HBM bandwidth.
+  f32x4 xn[NC];
+  u32x2 dn[NC];
+  float mu_n = 0.f, rs_n = 0.f;
+  auto issue = [&](int row) {
+    mu_n = mean[row];
+    rs_n = rstd[row];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int ci = lane + 64 * c;
+      if (ci < nchunk) {
+        xn[c] = *reinterpret_cast<const f32x4*>(x + (size_t)row * D + 4 * ci);
+        dn[c] = *reinterpret_cast<const u32x2*>(dy + (size_t)row * D + 4 * ci);
+      }
+    }
+  };
+  if (wave < M) issue(wave);
   for (int row = wave; row < M; row += nwaves) {
-    const float mu = mean[row], rs = rstd[row];
-    const float* xr = x + (size_t)row * D;
-    const bf16_t* dyr = dy + (size_t)row * D;
-    f32x4 xh[NC], gy[NC];
+    const float mu = mu_n, rs = rs_n;
+    f32x4 xh[NC], rv[NC];
+    u32x2 dw[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { xh[c] = xn[c]; dw[c] = dn[c]; }
+    if (row + nwaves < M) issue(row + nwaves);
+    if (dres != nullptr) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int ci = lane + 64 * c;
+        if (ci < nchunk) rv[c] = *reinterpret_cast<const f32x4*>(dres + (size_t)row * D + 4 * ci);
+      }
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int ci = lane + 64 * c;
       if (ci < nchunk) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + 4 * ci);
-        const u32x2 dw = *reinterpret_cast<const u32x2*>(dyr + 4 * ci);
-        const float d[4] = {bflo(dw[0]), bfhi(dw[0]), bflo(dw[1]), bfhi(dw[1])};
+        const float d[4] = {bflo(dw[c][0]), bfhi(dw[c][0]), bflo(dw[c][1]), bfhi(dw[c][1])};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          xh[c][e] = (xv[e] - mu) * rs;
-          gy[c][e] = d[e] * g[c][e];
-          s1 += gy[c][e];
-          s2 = fmaf(gy[c][e], xh[c][e], s2);
-          ag[c][e] = fmaf(d[e], xh[c][e], ag[c][e]);
+          const float xhat = (xh[c][e] - mu) * rs;
+          const float gy = d[e] * g[c][e];
+          xh[c][e] = xhat;
+          s1 += gy;
+          s2 = fmaf(gy, xhat, s2);
+          ag[c][e] = fmaf(d[e], xhat, ag[c][e]);
           ab[c][e] += d[e];
         }
       }
@@ -130,27 +155,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     for (int c = 0; c < NC; ++c) {
       const int ci = lane + 64 * c;
       if (ci < nchunk) {
+        const float d[4] = {bflo(dw[c][0]), bfhi(dw[c][0]), bflo(dw[c][1]), bfhi(dw[c][1])};
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rs * (gy[c][e] - m1 - xh[c][e] * m2);
+        for (int e = 0; e < 4; ++e) o[e] = rs * (d[e] * g[c][e] - m1 - xh[c][e] * m2);
         if (dres != nullptr) {
-          const f32x4 rv = *reinterpret_cast<const f32x4*>(dres + (size_t)row * D + 4 * ci);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] += rv[e];
+          for (int e = 0; e < 4; ++e) o[e] += rv[c][e];
         }
         *reinterpret_cast<f32x4*>(dx + (size_t)row * D + 4 * ci) = o;
         if (dxb != nullptr) {
           u32x2 wv = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
           *reinterpret_cast<u32x2*>(dxb + (size_t)row * D + 4 * ci) = wv;
         }
-        if (dxsum != nullptr) {
+        if (want_dxsum) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) as[c][e] += o[e];
         }
       }
     }
   }
-  // block reduction of the per-lane column partials, one chunk slot at a time
+  // block reduction of the per-lane column partials, one chunk slot at a time; each block writes its [3][D] partial
+  // sums to the workspace (a second tiny kernel folds them): 1024 workgroups adding atomically into the same 3 x D
+  // words ran at the contended-atomic rate and took 3/4 of this kernel's time.
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int ci = lane + 64 * c;
@@ -163,16 +190,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     }
     __syncthreads();
     if (w < 3 && ci < nchunk) {
-      float* dst = (w == 0) ? dgamma : (w == 1) ? dbeta : dxsum;
-      if (dst != nullptr) {
+      f32x4 t;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float t = (red[w][0][lane * 4 + e] + red[w][1][lane * 4 + e]) + (red[w][2][lane * 4 + e] + red[w][3][lane * 4 + e]);
-          unsafeAtomicAdd(dst + 4 * ci + e, t);
-        }
-      }
+      for (int e = 0; e < 4; ++e)
+        t[e] = (red[w][0][lane * 4 + e] + red[w][1][lane * 4 + e]) + (red[w][2][lane * 4 + e] + red[w][3][lane * 4 + e]);
+      *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 3 + w) * D + 4 * ci) = t;
     }
   }
+}
+
+// out_k[c] += sum_b partial[b][k][c] for k = 0 (dgamma), 1 (dbeta), 2 (dxsum); 64 columns x 4 block-groups per workgroup
+__global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* __restrict__ partial, int nblocks, int D,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float* __restrict__ dxsum) {
+  __shared__ float red[4][64];
+  const int k = blockIdx.y;
+  float* dst = (k == 0) ? dgamma : (k == 1) ? dbeta : dxsum;
+  if (dst == nullptr) return;
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s = 0.f;
+  if (c < D)
+    for (int b = grp; b < nblocks; b += 4) s += partial[((size_t)b * 3 + k) * D + c];
+  red[grp][cl] = s;
+  __syncthreads();
+  if (grp == 0 && c < D) dst[c] += (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
 static inline int ln_grid(int M) {
@@ -203,24 +245,35 @@ extern "C" int octmae_layernorm_fwd(const float* x, const float* gamma, const fl
   return 0;
 }
 
+extern "C" int octmae_layernorm_bwd_ws_floats(int M, int D) {
+  int blocks = ln_grid(M);
+  if (blocks > 512) blocks = 512;
+  return blocks * 3 * D;
+}
+
 extern "C" int octmae_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
                                     const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgamma,
-                                    float* dbeta, float* dxsum, int M, int D, void* stream) {
-  OCTMAE_CHECK_ARG(dy_bf16 && x && mean && rstd && gamma && dx);
+                                    float* dbeta, float* dxsum, float* partial_ws, int M, int D, void* stream) {
+  OCTMAE_CHECK_ARG(dy_bf16 && x && mean && rstd && gamma && dx && partial_ws);
   OCTMAE_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXC);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nc = (D / 4 + 63) / 64;
   const bf16_t* dy = reinterpret_cast<const bf16_t*>(dy_bf16);
   bf16_t* dxb = reinterpret_cast<bf16_t*>(dx_bf16);
   int blocks = ln_grid(M);
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 512) blocks = 512;
   dim3 grid(blocks), blk(256);
+  const bool ws = dxsum != nullptr;
   switch (nc) {
-    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, blk, 0, st, dy, x, mean, rstd, gamma, dres, dx, dxb, dgamma, dbeta, dxsum, M, D); break;
-    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, blk, 0, st, dy, x, mean, rstd, gamma, dres, dx, dxb, dgamma, dbeta, dxsum, M, D); break;
-    case 3: case 4: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, blk, 0, st, dy, x, mean, rstd, gamma, dres, dx, dxb, dgamma, dbeta, dxsum, M, D); break;
-    default: hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, blk, 0, st, dy, x, mean, rstd, gamma, dres, dx, dxb, dgamma, dbeta, dxsum, M, D); break;
+    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, blk, 0, st, dy, x, mean, rstd, gamma, dres, dx, dxb, partial_ws, ws, M, D); break;
+    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, blk, 0, st, dy, x, mean, rstd, gamma, dres, dx, dxb, partial_ws, ws, M, D); break;
+    case 3: case 4: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, blk, 0, st, dy, x, mean, rstd, gamma, dres, dx, dxb, partial_ws, ws, M, D); break;
+    default: hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, blk, 0, st, dy, x, mean, rstd, gamma, dres, dx, dxb, partial_ws, ws, M, D); break;
   }
   OCTMAE_LAUNCH_CHECK();
+  if (dgamma != nullptr || dbeta != nullptr || dxsum != nullptr) {
+    hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((D + 63) / 64, 3), dim3(256), 0, st, partial_ws, blocks, D, dgamma, dbeta, dxsum);
+    OCTMAE_LAUNCH_CHECK();
+  }
   return 0;
 }

@@ -210,8 +210,10 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None, want_bf16=
     M, D = x.shape
     dx = torch.empty((M, D), dtype=F32, device=x.device)
     dxb = torch.empty((M, D), dtype=BF16, device=x.device) if want_bf16 else None
+    from ._lib import load
+    ws = torch.empty((load().octmae_layernorm_bwd_ws_floats(M, D),), dtype=F32, device=x.device)
     call("octmae_layernorm_bwd", dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), _p(dres),
-         dx.data_ptr(), _p(dxb), _p(dgamma), _p(dbeta), _p(dxsum), M, D, _stream())
+         dx.data_ptr(), _p(dxb), _p(dgamma), _p(dbeta), _p(dxsum), ws.data_ptr(), M, D, _stream())
     return dx, dxb
 
 
@@ -288,9 +290,12 @@ class LayerNormFn(torch.autograd.Function):
         x2, mean, rstd, gamma, beta = ctx.saved_tensors
         D = x2.shape[1]
         dyb = _as2d_bf16(dy, D)
-        dx, _ = layernorm_bwd(dyb, x2, mean, rstd, gamma, grad_buf(gamma), grad_buf(beta))
+        colsum = torch.zeros(D, dtype=F32, device=x2.device)
+        dx, dxb = layernorm_bwd(dyb, x2, mean, rstd, gamma, grad_buf(gamma), grad_buf(beta), want_bf16=True, dxsum=colsum)
         notify_grad_ready((gamma, beta))
-        return dx.view(ctx.shp), None, None, None
+        dx = dx.view(ctx.shp)
+        _sidecar_put(dx, dxb.view(ctx.shp), colsum)      # the producing Block's backward takes these instead of redoing them
+        return dx, None, None, None
 
 
 class LinearFn(torch.autograd.Function):
@@ -424,6 +429,106 @@ class MlpFn(torch.autograd.Function):
         notify_grad_ready(ctx.params)
         dy = linear_dgrad(dpre, w1_lp).view(ctx.shp)
         return (dy, dout if ctx.has_res else None, None, None, None, None, None) + (None,) * len(ctx.params)
+
+
+# Gradients handed from one fused op to the one upstream of it, keyed by the fp32 gradient tensor they describe:
+#   data_ptr -> (weakref to that tensor, bf16 copy, column sums)
+# The consumer (the Block whose OUTPUT gradient this is) uses the pair only if the tensor autograd hands it is that very
+# tensor; if autograd summed other contributions into a new tensor the entry is ignored (and the work redone locally).
+import weakref
+
+_grad_sidecar = {}
+
+
+def _sidecar_put(dx: torch.Tensor, dxb: torch.Tensor, colsum: torch.Tensor):
+    if len(_grad_sidecar) > 64:
+        _grad_sidecar.clear()
+    _grad_sidecar[dx.data_ptr()] = (weakref.ref(dx), dxb, colsum)
+
+
+def _sidecar_take(d: torch.Tensor):
+    ent = _grad_sidecar.pop(d.data_ptr(), None)
+    if ent is None:
+        return None
+    ref, dxb, colsum = ent
+    if ref() is not d or dxb.shape != d.shape:
+        return None
+    return dxb, colsum
+
+
+class BlockFn(torch.autograd.Function):
+    """One pre-norm transformer Block (video_vit.py:181-184) as a single autograd node.
+
+    forward : x -> LN1 -> Wqkv -> attention -> proj (+x) -> LN2 -> fc1 + GELU -> fc2 (+x2)          (7 launches)
+    backward: the same chain in reverse with everything that only existed to please per-op autograd fused away:
+              both residual gradient adds and the bf16 gradient copy happen inside the LayerNorm backward kernels, which also
+              produce the proj / fc2 bias gradients (column sums of what they write); GELU' is the fc2-dgrad epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, H, eps1, eps2, lp, grads, *params):
+        shp = x.shape
+        C = shp[-1]
+        Bn, N = shp[0], shp[1]
+        HD = C // H
+        scale = HD ** -0.5
+        wqkv, bqkv, wproj, bproj, w1, b1, w2, b2 = lp
+        g1, be1, g2, be2 = params[0], params[1], params[2], params[3]
+        x2d = _chk(x.reshape(-1, C), F32, "block input")
+        y1, mean1, rstd1 = layernorm_fwd(x2d, g1, be1, eps1)
+        qkv = linear_fwd(y1, wqkv, bqkv, "bf16")
+        o, lse = attn_fwd(qkv, Bn, N, H, HD, scale)
+        x2 = linear_fwd(o, wproj, bproj, "resid", res=x2d)
+        y2, mean2, rstd2 = layernorm_fwd(x2, g2, be2, eps2)
+        pre, act = linear_fwd(y2, w1, b1, "gelu")
+        x3 = linear_fwd(act, w2, b2, "resid", res=x2)
+        ctx.save_for_backward(x2d, mean1, rstd1, y1, qkv, o, lse, x2, mean2, rstd2, y2, pre, act, wqkv, wproj, w1, w2, g1, g2)
+        ctx.meta = (Bn, N, H, HD, scale, shp)
+        ctx.grads, ctx.params = grads, params
+        return x3.view(shp)
+
+    @staticmethod
+    def backward(ctx, dx3):
+        x2d, mean1, rstd1, y1, qkv, o, lse, x2, mean2, rstd2, y2, pre, act, wqkv, wproj, w1, w2, g1, g2 = ctx.saved_tensors
+        Bn, N, H, HD, scale, shp = ctx.meta
+        C = H * HD
+        (gg1, gb1n, gg2, gb2n, gwqkv, gbqkv, gwproj, gbproj, gw1, gb1, gw2, gb2) = ctx.grads()
+        if dx3.dtype != F32 or not dx3.is_contiguous():
+            dx3 = dx3.contiguous().float()
+        side = _sidecar_take(dx3)
+        d3 = dx3.view(-1, C)
+        if side is not None:                     # produced by the LayerNorm backward of the next Block
+            d3b, colsum3 = side
+            d3b = d3b.view(-1, C)
+            if gb2 is not None:
+                gb2.add_(colsum3)
+        else:
+            d3b = cast_bf16(d3)
+            if gb2 is not None:
+                colsum_accum(d3, gb2)
+        # ---- MLP
+        linear_wgrad_accum(d3b, act, gw2)
+        dpre = linear_dgrad(d3b, w2, pre=pre)
+        if gb1 is not None:
+            colsum_accum(dpre, gb1)
+        linear_wgrad_accum(dpre, y2, gw1)
+        dy2 = linear_dgrad(dpre, w1)
+        # ---- LN2 backward + residual add + bf16 copy + proj bias gradient
+        dx2, dx2b = layernorm_bwd(dy2, x2, mean2, rstd2, g2, gg2, gb2n, dres=d3, want_bf16=True, dxsum=gbproj)
+        # ---- attention
+        linear_wgrad_accum(dx2b, o, gwproj)
+        do = linear_dgrad(dx2b, wproj)
+        dqkv = attn_bwd(qkv, o, do, lse, Bn, N, H, HD, scale)
+        if gbqkv is not None:
+            colsum_accum(dqkv, gbqkv)
+        linear_wgrad_accum(dqkv, y1, gwqkv)
+        dy1 = linear_dgrad(dqkv, wqkv)
+        # ---- LN1 backward + residual add; its bf16 copy / column sums are what the previous Block's backward needs
+        colsum = torch.zeros(C, dtype=F32, device=dx3.device)
+        dx, dxb = layernorm_bwd(dy1, x2d, mean1, rstd1, g1, gg1, gb1n, dres=dx2, want_bf16=True, dxsum=colsum)
+        notify_grad_ready(ctx.params)
+        dx = dx.view(shp)
+        _sidecar_put(dx, dxb.view(shp), colsum)
+        return (dx, None, None, None, None, None) + (None,) * len(ctx.params)
 
 
 class EncAssembleFn(torch.autograd.Function):

@@ -185,11 +185,31 @@ class Block(nn.Module):
         self.norm2 = norm_layer(dim)
         mlp_hidden_dim = int(dim * mlp_ratio)
         self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer, drop=drop)
+        self._views = None
+
+    def _v(self):
+        arena = get_arena(self)
+        if getattr(self, "_views", None) is None or self._views[0] is not arena:
+            a, m = self.attn, self.mlp
+            _, wqkv, bqkv, wproj, bproj, agrads, aparams = a._v()
+            _, w1, b1, w2, b2, mgrads, mparams = m._v()
+            n1, n2 = self.norm1, self.norm2
+
+            def grads():
+                return (arena.grad_view(n1.weight), arena.grad_view(n1.bias), arena.grad_view(n2.weight), arena.grad_view(n2.bias)) + \
+                    agrads() + mgrads()
+            params = (n1.weight, n1.bias, n2.weight, n2.bias) + tuple(aparams) + tuple(mparams)
+            object.__setattr__(self, "_views", (arena, (wqkv, bqkv, wproj, bproj, w1, b1, w2, b2), grads, params))
+        return self._views
 
     def forward(self, x):
         if x.dtype != torch.float32:
             x = x.float()
         x = x.contiguous()
+        fused = isinstance(self.attn, Attention) and isinstance(self.norm1, nn.LayerNorm) and isinstance(self.norm2, nn.LayerNorm)
+        if (isinstance(self.drop_path, nn.Identity) or not self.training) and fused:
+            _, lp, grads, params = self._v()
+            return ops.BlockFn.apply(x, self.attn.num_heads, self.norm1.eps, self.norm2.eps, lp, grads, *params)
         if isinstance(self.drop_path, nn.Identity) or not self.training:
             x = self.attn(layer_norm(self.norm1, x), residual=x)
             x = self.mlp(layer_norm(self.norm2, x), residual=x)

@@ -201,7 +201,9 @@ def test_attention_fwd_bwd(HD, N):
     qd = qkv.double().requires_grad_(True)
     o_ref, lse_ref = attn_ref(qd, B, N, H, HD)
     assert rel(o, o_ref) < 4e-3                                   # bf16 P and bf16 output
-    assert float((lse.double() - lse_ref).abs().max()) < 2e-3
+    # the kernels round q * scale * log2(e) to bf16 once more (the exp2 argument comes straight out of the MFMA): score error
+    # ~ 2^-9 |s|, so LSE is compared relative to its magnitude
+    assert float((lse.double() - lse_ref).abs().max()) < 4e-3 * (1.0 + float(lse_ref.abs().max()))
     o_ref.backward(do.double())
     dqkv = ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, HD ** -0.5)
     got = dqkv.double().view(B, N, 3, H * HD); ref = qd.grad.view(B, N, 3, H * HD)
@@ -225,7 +227,7 @@ def test_attention_online_softmax_rescale_branch(HD):
     o, lse = ops.attn_fwd(qkv, B, N, H, HD, HD ** -0.5)
     o_ref, lse_ref = attn_ref(qkv, B, N, H, HD)
     assert torch.isfinite(o).all()
-    assert rel(o, o_ref) < 5e-3 and float((lse.double() - lse_ref).abs().max()) < 5e-2
+    assert rel(o, o_ref) < 5e-3 and float((lse.double() - lse_ref).abs().max()) < 4e-3 * (1.0 + float(lse_ref.abs().max()))
 
 
 # ------------------------------------------------------------------------------------------------ masking (bit-exact)
