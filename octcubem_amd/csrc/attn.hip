@@ -190,8 +190,8 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 2)) void attn_fwd_
   };
 
   // tile t: scur = S_t (already computed), snext <- S_{t+1}
-  auto step = [&](int t, f32x16 (&scur)[2], f32x16 (&snext)[2]) {
-    const bool last = (t + 1 == ntiles);
+  auto step = [&](int t, f32x16 (&scur)[2], f32x16 (&snext)[2], auto last_tag) {
+    constexpr bool last = decltype(last_tag)::value;             // compile-time: the masking code must not leak into the loop
     const char* cV = Vbuf + (t & 1) * T::BYTES;
     if (last) {                                                  // only the last tile can hold keys >= N
 #pragma unroll
@@ -261,9 +261,16 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 2)) void attn_fwd_
 
   f32x16 sA[2], sB[2];
   qk(Kbuf, sA);
-  for (int t = 0; t < ntiles; t += 2) {
-    step(t, sA, sB);
-    if (t + 1 < ntiles) step(t + 1, sB, sA);
+  int t = 0;
+  for (; t + 2 < ntiles; t += 2) {
+    step(t, sA, sB, std::false_type{});
+    step(t + 1, sB, sA, std::false_type{});
+  }
+  if (t + 1 < ntiles) {
+    step(t, sA, sB, std::false_type{});
+    step(t + 1, sB, sA, std::true_type{});
+  } else {
+    step(t, sA, sB, std::true_type{});
   }
 
   // every row of the ones-MFMA accumulator holds the full row sum (both lane halves); the VALU form is per half
