@@ -86,10 +86,11 @@ int octmae_patch_gather(const float* imgs, const void* ids, int ids_is_i64, void
 /* encoder input: cls concat + gathered sep pos-embed add, models_mae_joint_res_flash_attn.py:409-478 */
 int octmae_enc_assemble(const void* tok_bf16, const float* pos, const float* cls, const float* pos_cls,
                         const long long* ids_keep, float* x, int B, int nkeep, int D, void* stream);
-/* decoder input: mask tokens + un-shuffle + cls + pos-embed, models_mae_joint_res_flash_attn.py:515-573 */
+/* decoder input: mask tokens + un-shuffle + cls + pos-embed, models_mae_joint_res_flash_attn.py:515-573.
+ * emb_has_cls = 1 (2-D MAE, OCTCube/models_mae.py:175-178): emb has 1 + nkeep rows per sample, row 0 is the cls row. */
 int octmae_dec_assemble(const void* emb_bf16, const float* mask_token, const float* dpos, const float* dcls,
                         const float* dpos_cls, const long long* ids_restore, float* x, int B, int nkeep, int L, int D,
-                        void* stream);
+                        int emb_has_cls, void* stream);
 /* out bf16[b*n+i][:] = src f32[b][1+ids[b][i]][:]  (backward of both assemblies w.r.t. the token rows) */
 int octmae_gather_rows_cast(const float* src, const long long* ids, void* out_bf16, int B, int n, int src_rows, int D,
                             void* stream);

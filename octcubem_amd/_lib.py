@@ -30,7 +30,7 @@ SIGNATURES = {
     "octmae_colsum_accum": [_vp, _i, _vp, _i, _i, _i, _vp],
     "octmae_patch_gather": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "octmae_enc_assemble": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "octmae_dec_assemble": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "octmae_dec_assemble": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "octmae_gather_rows_cast": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "octmae_mse_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "octmae_mse_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

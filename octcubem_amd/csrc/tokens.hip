@@ -131,7 +131,10 @@ template <typename IdxT>
 __global__ __launch_bounds__(256) void dec_assemble_kernel(const bf16_t* __restrict__ emb, const float* __restrict__ mask_token,
                                                            const float* __restrict__ dpos, const float* __restrict__ dcls,
                                                            const float* __restrict__ dpos_cls, const IdxT* __restrict__ ids_restore,
-                                                           float* __restrict__ x, int B, int nkeep, int L, int D) {
+                                                           float* __restrict__ x, int B, int nkeep, int L, int D, int emb_has_cls) {
+  // emb_has_cls (2-D MAE, OCTCube/models_mae.py:175-178): emb holds 1 + nkeep rows per sample and row 0 (the encoder's cls
+  // token after decoder_embed) becomes the decoder cls row; otherwise the cls row is the parameter `dcls`.
+  const int erows = nkeep + (emb_has_cls ? 1 : 0);
   const int d4 = D >> 2;
   const size_t total = (size_t)B * (L + 1) * d4;
   for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
@@ -140,12 +143,18 @@ __global__ __launch_bounds__(256) void dec_assemble_kernel(const bf16_t* __restr
     const int b = (int)(row / (L + 1)), j = (int)(row % (L + 1));
     f32x4 o;
     if (j == 0) {
-      o = *reinterpret_cast<const f32x4*>(dcls + 4 * c) + *reinterpret_cast<const f32x4*>(dpos_cls + 4 * c);
+      const f32x4 pc = *reinterpret_cast<const f32x4*>(dpos_cls + 4 * c);
+      if (emb_has_cls) {
+        const u32x2 w = *reinterpret_cast<const u32x2*>(emb + ((size_t)b * erows) * D + 4 * c);
+        o[0] = bflo(w[0]) + pc[0]; o[1] = bfhi(w[0]) + pc[1]; o[2] = bflo(w[1]) + pc[2]; o[3] = bfhi(w[1]) + pc[3];
+      } else {
+        o = *reinterpret_cast<const f32x4*>(dcls + 4 * c) + pc;
+      }
     } else {
       const int r = (int)ids_restore[(size_t)b * L + j - 1];
       const f32x4 pv = *reinterpret_cast<const f32x4*>(dpos + (size_t)(j - 1) * D + 4 * c);
       if (r < nkeep) {
-        const u32x2 w = *reinterpret_cast<const u32x2*>(emb + ((size_t)b * nkeep + r) * D + 4 * c);
+        const u32x2 w = *reinterpret_cast<const u32x2*>(emb + ((size_t)b * erows + (emb_has_cls ? 1 : 0) + r) * D + 4 * c);
         o[0] = bflo(w[0]) + pv[0]; o[1] = bfhi(w[0]) + pv[1]; o[2] = bflo(w[1]) + pv[2]; o[3] = bfhi(w[1]) + pv[3];
       } else {
         o = *reinterpret_cast<const f32x4*>(mask_token + 4 * c) + pv;
@@ -346,13 +355,13 @@ extern "C" int octmae_enc_assemble(const void* tok_bf16, const float* pos, const
 
 extern "C" int octmae_dec_assemble(const void* emb_bf16, const float* mask_token, const float* dpos, const float* dcls,
                                    const float* dpos_cls, const long long* ids_restore, float* x, int B, int nkeep, int L,
-                                   int D, void* stream) {
-  OCTMAE_CHECK_ARG(emb_bf16 && mask_token && dpos && dcls && dpos_cls && ids_restore && x);
+                                   int D, int emb_has_cls, void* stream) {
+  OCTMAE_CHECK_ARG(emb_bf16 && mask_token && dpos && (dcls || emb_has_cls) && dpos_cls && ids_restore && x);
   OCTMAE_CHECK_ARG(B > 0 && nkeep > 0 && L >= nkeep && D % 4 == 0);
   const size_t total = (size_t)B * (L + 1) * (D / 4);
   hipLaunchKernelGGL(dec_assemble_kernel<long long>, dim3(grid_for(total, 256, 8192)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16_t*>(emb_bf16), mask_token, dpos,
-                     dcls, dpos_cls, ids_restore, x, B, nkeep, L, D);
+                     dcls, dpos_cls, ids_restore, x, B, nkeep, L, D, emb_has_cls);
   OCTMAE_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,121 @@
+"""Spatio-temporal ViT for fine-tuning / inference: drop-in for the reference's
+``OCTCube/models_vit_st_flash_attn.py`` ``VisionTransformer`` (constructor :51-178, forward :181-258) with the non-flash
+(standard residual) semantics.  No masking: all T*H*W + 1 tokens go through every block (5121 tokens for 60x256x256).
+Same state_dict keys; ``forward(x, hidden_states=False, return_embeddings=False)``.  GPU only."""
+from __future__ import annotations
+
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from . import ops, video_vit
+from .arena import get_arena
+from .video_vit import Attention, Block, PatchEmbed
+
+
+class VisionTransformer(nn.Module):
+    """Vision Transformer with support for global average pooling"""
+
+    def __init__(self, num_frames, t_patch_size, img_size=256, patch_size=16, in_chans=1, num_classes=400, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4.0, no_qkv_bias=False, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
+                 drop_path_rate=0.0, norm_layer=nn.LayerNorm, dropout=0.5, sep_pos_embed=False, cls_embed=False,
+                 global_pool=False, use_flash_attn=False, **kwargs):
+        super().__init__()
+        if not (sep_pos_embed and cls_embed):
+            raise NotImplementedError("built for sep_pos_embed=True, cls_embed=True (how every reference script calls it)")
+        self.global_pool = global_pool
+        self.sep_pos_embed = sep_pos_embed
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim, num_frames, t_patch_size)
+        input_size = self.patch_embed.input_size
+        self.input_size = input_size
+        self.cls_embed = cls_embed
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed_spatial = nn.Parameter(torch.zeros(1, input_size[1] * input_size[2], embed_dim))
+        self.pos_embed_temporal = nn.Parameter(torch.zeros(1, input_size[0], embed_dim))
+        self.pos_embed_class = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        self.use_flash_attn = False     # attention is always the fused gfx950 kernel (standard residual semantics)
+        self.blocks = nn.ModuleList([
+            Block(embed_dim, num_heads, mlp_ratio, qkv_bias=not no_qkv_bias, qk_scale=None, norm_layer=norm_layer, drop_path=dpr[i],
+                  attn_func=partial(Attention, input_size=self.patch_embed.input_size)) for i in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.dropout = nn.Dropout(dropout)
+        self.head = nn.Linear(embed_dim, num_classes)
+        torch.nn.init.normal_(self.head.weight, std=0.02)
+        self._ids = None
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {"cls_token", "pos_embed", "pos_embed_spatial", "pos_embed_temporal", "pos_embed_class"}
+
+    def prepare(self):
+        arena = get_arena(self, full_check=True)
+        if torch.is_grad_enabled():
+            arena.rebind_grads()
+        arena.refresh_lp()
+        return arena
+
+    @property
+    def arena(self):
+        return get_arena(self, full_check=True)
+
+    def forward(self, x, hidden_states=False, return_embeddings=False):
+        arena = self.prepare()
+        x = x.float().contiguous()
+        N = x.shape[0]
+        T, h, w = self.input_size
+        L = T * h * w
+        tok = self.patch_embed.embed_tokens(x)                                         # bf16 [N*L, C], all tokens
+        pos = (self.pos_embed_spatial.repeat(1, T, 1) + torch.repeat_interleave(self.pos_embed_temporal, h * w, dim=1)).view(L, -1)
+        if self._ids is None or self._ids.shape[0] != N or self._ids.device != x.device:
+            object.__setattr__(self, "_ids", torch.arange(L, device=x.device, dtype=torch.int64).expand(N, L).contiguous())
+        x = ops.EncAssembleFn.apply(tok, pos, self.cls_token, self.pos_embed_class, self._ids)   # fp32 [N, 1+L, C]
+        hidden_states_list = []
+        for blk in self.blocks:
+            x = blk(x)
+            hidden_states_list.append(x)
+        if hidden_states:
+            return hidden_states_list
+        if self.global_pool:
+            x = x[:, 1:, :].mean(dim=1)      # global pool without cls token; the reference's norm(x) here is computed and unused
+        else:
+            x = x[:, 0]
+        embedding = x
+        x = self.dropout(x)
+        hw, hb = arena.lp_view(self.head.weight), arena.f32_view(self.head.bias)
+        x = ops.LinearFn.apply(x, hw, hb, lambda: arena.grad_view(self.head.weight), lambda: arena.grad_view(self.head.bias), True,
+                               self.head.weight, self.head.bias)
+        if return_embeddings:
+            return x, embedding
+        return x
+
+    def load_state_dict_to_backbone(self, state_dict, strict=False, filter_keys=()):
+        """Accepts flash-layout keys (mixer.Wqkv / mixer.out_proj) as well as the native attn.q/k/v/proj layout."""
+        sd = {}
+        for k, v in state_dict.items():
+            k = k.replace(".mixer.out_proj.", ".attn.proj.")
+            if ".mixer.Wqkv." in k:
+                kind = k.rsplit(".", 1)[1]
+                pre = k.split(".mixer.Wqkv.")[0]
+                for i, n in enumerate("qkv"):
+                    sd[f"{pre}.attn.{n}.{kind}"] = v.chunk(3, dim=0)[i].clone()
+                continue
+            sd[k] = v
+        sd = {k: v for k, v in sd.items() if not any(f in k for f in filter_keys)}
+        return super().load_state_dict(sd, strict=strict)
+
+
+def vit_base_patch16(**kwargs):
+    return VisionTransformer(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4,
+                             norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def vit_large_patch16(**kwargs):
+    return VisionTransformer(patch_size=16, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4,
+                             norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def flash_attn_vit_large_patch16(**kwargs):
+    kwargs.pop("use_flash_attn", None)
+    return vit_large_patch16(**kwargs)

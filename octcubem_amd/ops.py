@@ -106,6 +106,7 @@ def _launch(kind, flops, nbytes, fn):
 def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     if x.dtype == BF16:
         return x.contiguous()
+    x = x.contiguous()
     _chk(x, F32, "cast_bf16")
     out = torch.empty(x.shape, dtype=BF16, device=x.device)
     call("octmae_cast_f32_bf16", x.data_ptr(), out.data_ptr(), x.numel(), _stream())
@@ -562,7 +563,9 @@ class EncAssembleFn(torch.autograd.Function):
 
 
 class DecAssembleFn(torch.autograd.Function):
-    """mask-token append, un-shuffle, cls concat, positional embedding (models_mae_joint_res_flash_attn.py:515-573)."""
+    """mask-token append, un-shuffle, cls concat, positional embedding (models_mae_joint_res_flash_attn.py:515-573).
+    ``dcls is None``: the 2-D MAE form (OCTCube/models_mae.py:175-178) -- emb carries 1 + nkeep rows per sample and its
+    row 0 is the cls row."""
 
     @staticmethod
     def forward(ctx, emb, mask_token, dpos, dcls, dpos_cls, ids_restore, ids_keep):
@@ -572,10 +575,10 @@ class DecAssembleFn(torch.autograd.Function):
         _chk(emb, BF16, "decoder tokens")
         dpos2 = _chk(dpos.reshape(-1, D), F32, "decoder pos table")
         x = torch.empty((Bn, L + 1, D), dtype=F32, device=emb.device)
-        call("octmae_dec_assemble", emb.data_ptr(), mask_token.data_ptr(), dpos2.data_ptr(), dcls.data_ptr(), dpos_cls.data_ptr(),
-             ids_restore.data_ptr(), x.data_ptr(), Bn, nkeep, L, D, _stream())
+        call("octmae_dec_assemble", emb.data_ptr(), mask_token.data_ptr(), dpos2.data_ptr(), _p(dcls), dpos_cls.data_ptr(),
+             ids_restore.data_ptr(), x.data_ptr(), Bn, nkeep, L, D, 1 if dcls is None else 0, _stream())
         ctx.save_for_backward(ids_restore, ids_keep)
-        ctx.shapes = (mask_token.shape, dpos.shape, dcls.shape, dpos_cls.shape)
+        ctx.shapes = (mask_token.shape, dpos.shape, None if dcls is None else dcls.shape, dpos_cls.shape)
         return x
 
     @staticmethod
@@ -584,15 +587,20 @@ class DecAssembleFn(torch.autograd.Function):
         dx = dx.contiguous()
         Bn, L1, D = dx.shape
         nkeep = ids_keep.shape[1]
-        demb = torch.empty((Bn * nkeep, D), dtype=BF16, device=dx.device)
-        call("octmae_gather_rows_cast", dx.data_ptr(), ids_keep.data_ptr(), demb.data_ptr(), Bn, nkeep, L1, D, _stream())
+        ms, ps, cs, pcs = ctx.shapes
+        if cs is None:      # cls row travels with the tokens: ids = [-1, ids_keep]  (source row = 1 + id)
+            ids = torch.cat([ids_keep.new_full((Bn, 1), -1), ids_keep], dim=1).contiguous()
+            demb = torch.empty((Bn * (nkeep + 1), D), dtype=BF16, device=dx.device)
+            call("octmae_gather_rows_cast", dx.data_ptr(), ids.data_ptr(), demb.data_ptr(), Bn, nkeep + 1, L1, D, _stream())
+        else:
+            demb = torch.empty((Bn * nkeep, D), dtype=BF16, device=dx.device)
+            call("octmae_gather_rows_cast", dx.data_ptr(), ids_keep.data_ptr(), demb.data_ptr(), Bn, nkeep, L1, D, _stream())
         body = dx[:, 1:, :]
         masked = (ids_restore >= nkeep).to(F32).unsqueeze(-1)
         dmask = (body * masked).sum((0, 1))
         ddpos = body.sum(0)
         dc = dx[:, 0, :].sum(0)
-        ms, ps, cs, pcs = ctx.shapes
-        return demb, dmask.view(ms), ddpos.view(ps), dc.view(cs), dc.view(pcs).clone(), None, None
+        return (demb, dmask.view(ms), ddpos.view(ps), None if cs is None else dc.view(cs), dc.view(pcs).clone(), None, None)
 
 
 class PatchMSEFn(torch.autograd.Function):

@@ -135,6 +135,80 @@ class Attention(nn.Module):
         return ops.AttentionFn.apply(x, residual, wqkv, bqkv, wproj, bproj, grads, self.num_heads, *params)
 
 
+class TimmAttention(nn.Module):
+    """timm 0.3.2 ``vision_transformer.Attention`` (one fused ``qkv`` Linear) -- the block the reference's 2-D models build
+    from ``timm.models.vision_transformer.Block`` (OCTCube/models_mae.py:18,40-42).  Same kernels as ``Attention``."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        if head_dim not in (32, 64):
+            raise NotImplementedError("the gfx950 attention kernels are built for head_dim 32 and 64")
+        if qk_scale is not None and abs(qk_scale - head_dim ** -0.5) > 1e-12:
+            raise NotImplementedError("qk_scale other than head_dim**-0.5")
+        assert attn_drop == 0.0 and proj_drop == 0.0
+        self.scale = qk_scale or head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self._views = None
+
+    def _v(self):
+        arena = get_arena(self)
+        if self._views is None or self._views[0] is not arena:
+            qkv, pr = self.qkv, self.proj
+            has_b = qkv.bias is not None
+
+            def grads():
+                return (arena.grad_view(qkv.weight), arena.grad_view(qkv.bias) if has_b else None, arena.grad_view(pr.weight),
+                        arena.grad_view(pr.bias) if pr.bias is not None else None)
+            params = [qkv.weight, pr.weight] + ([qkv.bias] if has_b else []) + ([pr.bias] if pr.bias is not None else [])
+            object.__setattr__(self, "_views", (arena, arena.lp_view(qkv.weight), arena.f32_view(qkv.bias) if has_b else None,
+                                                arena.lp_view(pr.weight), arena.f32_view(pr.bias) if pr.bias is not None else None,
+                                                grads, tuple(params)))
+        return self._views
+
+    def forward(self, x, residual=None):
+        _, wqkv, bqkv, wproj, bproj, grads, params = self._v()
+        return ops.AttentionFn.apply(x, residual, wqkv, bqkv, wproj, bproj, grads, self.num_heads, *params)
+
+
+class TimmPatchEmbed(nn.Module):
+    """timm 0.3.2 ``PatchEmbed``: Conv2d(k = s = patch) + flatten(2).transpose(1, 2), as gather + MFMA GEMM."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        img_size = to_2tuple(img_size)
+        patch_size = to_2tuple(patch_size)
+        self.img_size = img_size
+        self.patch_size = patch_size
+        self.num_patches = (img_size[1] // patch_size[1]) * (img_size[0] // patch_size[0])
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self._views = None
+
+    def _v(self):
+        arena = get_arena(self)
+        if self._views is None or self._views[0] is not arena:
+            w, b = self.proj.weight, self.proj.bias
+            object.__setattr__(self, "_views", (arena, arena.lp_view(w, shape=(w.shape[0], -1)), arena.f32_view(b),
+                                                lambda: arena.grad_view(w), lambda: arena.grad_view(b)))
+        return self._views
+
+    def embed_tokens(self, x, ids_keep=None):
+        B, C, H, W = x.shape
+        assert H == self.img_size[0] and W == self.img_size[1], \
+            f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
+        _, w_lp, b32, gw, gb = self._v()
+        nkeep = self.num_patches if ids_keep is None else ids_keep.shape[1]
+        return ops.PatchEmbedFn.apply(x.contiguous().view(B, C, 1, H, W), ids_keep, w_lp, b32, gw, gb, 1, self.patch_size[0], nkeep,
+                                      self.proj.weight, self.proj.bias)
+
+    def forward(self, x):
+        return self.embed_tokens(x).view(x.shape[0], self.num_patches, -1)
+
+
 class Mlp(nn.Module):
     """timm.models.vision_transformer.Mlp: fc1 -> act -> drop -> fc2 -> drop (act = exact-erf GELU)."""
 
@@ -206,7 +280,8 @@ class Block(nn.Module):
         if x.dtype != torch.float32:
             x = x.float()
         x = x.contiguous()
-        fused = isinstance(self.attn, Attention) and isinstance(self.norm1, nn.LayerNorm) and isinstance(self.norm2, nn.LayerNorm)
+        fused = isinstance(self.attn, (Attention, TimmAttention)) and isinstance(self.norm1, nn.LayerNorm) and \
+            isinstance(self.norm2, nn.LayerNorm)
         if (isinstance(self.drop_path, nn.Identity) or not self.training) and fused:
             _, lp, grads, params = self._v()
             return ops.BlockFn.apply(x, self.attn.num_heads, self.norm1.eps, self.norm2.eps, lp, grads, *params)
@@ -217,3 +292,12 @@ class Block(nn.Module):
             x = x + self.drop_path(self.attn(layer_norm(self.norm1, x)).float())
             x = x + self.drop_path(self.mlp(layer_norm(self.norm2, x)).float())
         return x
+
+
+class TimmBlock(Block):
+    """timm 0.3.2 ``vision_transformer.Block`` signature (OCTCube/models_mae.py:40-42,54-56): fused-qkv attention."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, qk_scale=None, drop=0.0, attn_drop=0.0, drop_path=0.0,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__(dim, num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop, attn_drop=attn_drop,
+                         drop_path=drop_path, act_layer=act_layer, norm_layer=norm_layer, attn_func=TimmAttention)

@@ -81,8 +81,64 @@ def install_shims():
         def forward(self, x):
             return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
 
+    class TimmAttention(nn.Module):     # timm 0.3.2 vision_transformer.Attention
+        def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0):
+            super().__init__()
+            self.num_heads = num_heads
+            head_dim = dim // num_heads
+            self.scale = qk_scale or head_dim ** -0.5
+            self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+            self.attn_drop = nn.Dropout(attn_drop)
+            self.proj = nn.Linear(dim, dim)
+            self.proj_drop = nn.Dropout(proj_drop)
+
+        def forward(self, x):
+            B, N, C = x.shape
+            qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+            q, k, v = qkv[0], qkv[1], qkv[2]
+            attn = (q @ k.transpose(-2, -1)) * self.scale
+            attn = self.attn_drop(attn.softmax(dim=-1))
+            x = (attn @ v).transpose(1, 2).reshape(B, N, C)
+            return self.proj_drop(self.proj(x))
+
+    class TimmBlock(nn.Module):         # timm 0.3.2 vision_transformer.Block
+        def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, qk_scale=None, drop=0.0, attn_drop=0.0, drop_path=0.0,
+                     act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+            super().__init__()
+            self.norm1 = norm_layer(dim)
+            self.attn = TimmAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+            self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+            self.norm2 = norm_layer(dim)
+            self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+        def forward(self, x):
+            x = x + self.drop_path(self.attn(self.norm1(x)))
+            return x + self.drop_path(self.mlp(self.norm2(x)))
+
+    class TimmPatchEmbed(nn.Module):    # timm 0.3.2 vision_transformer.PatchEmbed
+        def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+            super().__init__()
+            img_size = to_2tuple(img_size); patch_size = to_2tuple(patch_size)
+            self.img_size = img_size; self.patch_size = patch_size
+            self.num_patches = (img_size[1] // patch_size[1]) * (img_size[0] // patch_size[0])
+            self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+        def forward(self, x):
+            return self.proj(x).flatten(2).transpose(1, 2)
+
     layers.to_2tuple = to_2tuple; tl.to_2tuple = to_2tuple
-    vt.DropPath = DropPath; vt.Mlp = Mlp
+    vt.DropPath = DropPath; vt.Mlp = Mlp; vt.PatchEmbed = TimmPatchEmbed; vt.Block = TimmBlock
+    tv = mod("torchvision"); tvt = mod("torchvision.transforms"); tv.transforms = tvt
+
+    class _Permissive:      # OCTCube/util/misc.py builds image transforms at import time (e.g. tf.Lambda); never called here
+        def __init__(self, *a, **k): pass
+        def __call__(self, *a, **k): raise RuntimeError("torchvision is not installed")
+    def _tv_getattr(name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Permissive
+    tvt.__getattr__ = _tv_getattr
+    tvt.__file__ = "<shim>"; tv.__file__ = "<shim>"
 
     fa = mod("flash_attn"); fam = mod("flash_attn.models"); fav = mod("flash_attn.models.vit")
     fa.models = fam; fam.vit = fav
@@ -274,6 +330,75 @@ def main():
                         no_decay=json.dumps(no_decay), decay=json.dumps(decay), lr_epochs=np.array(eps_),
                         lr_values=np.array(lrs), **after)
     print("train utils: grad_norm", float(gn), "groups", len(no_decay), len(decay))
+
+    # ------------------------------------------------------------------ ST fine-tune ViT + 2-D MAE (OCTCube/)
+    OC = "/root/reference/OCTCube"
+    for m_ in [k for k in list(sys.modules) if k == "util" or k.startswith("util.")]:
+        del sys.modules[m_]
+    sys.path.insert(0, OC)
+    os.chdir(OC)
+    from functools import partial
+    from oracle import vit_ref as V
+    import models_vit_st_flash_attn as ref_st
+    cfgS = V.ViTSTConfig(num_frames=12, t_patch_size=3, img_size=64, patch_size=16, in_chans=1, num_classes=8, embed_dim=128,
+                         depth=2, num_heads=2, global_pool=True)
+    mS = ref_st.VisionTransformer(num_frames=12, t_patch_size=3, img_size=64, patch_size=16, in_chans=1, num_classes=8,
+                                  embed_dim=128, depth=2, num_heads=2, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                                  sep_pos_embed=True, cls_embed=True, global_pool=True, drop_path_rate=0.0)
+    PS = V.init_from_shapes(V.vit_st_param_shapes(cfgS), seed=21)
+    mS.load_state_dict(PS, strict=True)
+    mS.eval()
+    xs = torch.rand(3, 1, 12, 64, 64, generator=torch.Generator().manual_seed(5))
+    logits, emb = mS(xs, return_embeddings=True)
+    tgt = torch.tensor([1, 5, 2])
+    lossS = torch.nn.functional.cross_entropy(logits, tgt)
+    mS.zero_grad(); lossS.backward()
+    gS = {k: p.grad for k, p in mS.named_parameters() if p.grad is not None}
+    mS2 = ref_st.VisionTransformer(num_frames=12, t_patch_size=3, img_size=64, patch_size=16, in_chans=1, num_classes=8,
+                                   embed_dim=128, depth=2, num_heads=2, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                                   sep_pos_embed=True, cls_embed=True, global_pool=False)
+    mS2.load_state_dict(PS, strict=True); mS2.eval()
+    logits_cls = mS2(xs)
+    saveS = {"param_seed": 21, "x": xs.numpy(), "logits": logits.detach().numpy(), "embedding": emb.detach().numpy(),
+             "logits_cls": logits_cls.detach().numpy(), "target": tgt.numpy(), "loss": lossS.detach().numpy(),
+             "cfg": json.dumps(cfgS.__dict__),
+             "param_checksum": np.array([float(v.double().sum()) for v in PS.values()]).sum()}
+    for k, v in gS.items():
+        saveS[f"gnorm/{k}"] = float(v.double().norm())
+        saveS[f"grad/{k}"] = v.numpy() if v.numel() <= 8192 else v.flatten()[::7].numpy()
+    np.savez_compressed(os.path.join(out_dir, "vit_st_small.npz"), **saveS)
+    print("ST ViT: logits", logits.detach().numpy()[0, :3], "loss", float(lossS))
+
+    import models_mae as ref_2d
+    cfg2 = V.MAE2DConfig(img_size=64, patch_size=16, in_chans=3, embed_dim=128, depth=2, num_heads=2, decoder_embed_dim=64,
+                         decoder_depth=2, decoder_num_heads=2)
+    m2d = ref_2d.MaskedAutoencoderViT(img_size=64, patch_size=16, in_chans=3, embed_dim=128, depth=2, num_heads=2,
+                                      decoder_embed_dim=64, decoder_depth=2, decoder_num_heads=2, mlp_ratio=4,
+                                      norm_layer=partial(nn.LayerNorm, eps=1e-6))
+    P2 = V.mae2d_init(cfg2, seed=31)
+    m2d.load_state_dict(P2, strict=True)
+    assert torch.allclose(m2d.pos_embed, P2["pos_embed"]) and set(m2d.state_dict()) == set(P2)
+    x2 = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(6))        # BASELINE config 1: randn B-scans
+    for sd in range(7000, 8000):
+        torch.manual_seed(sd)
+        nz2 = torch.rand(2, cfg2.num_patches)
+        if tie_free(nz2):
+            break
+    torch.manual_seed(sd)
+    loss2, pred2, mask2 = m2d(x2, mask_ratio=0.75)
+    m2d.zero_grad(); loss2.backward()
+    torch.manual_seed(sd)
+    _, _, ir2 = m2d.random_masking(torch.zeros(2, cfg2.num_patches, 4), 0.75)
+    save2 = {"param_seed": 31, "imgs": x2.numpy(), "noise": nz2.numpy(), "loss": loss2.detach().numpy(), "pred": pred2.detach().numpy(),
+             "mask": mask2.numpy(), "ids_restore": ir2.numpy(), "cfg": json.dumps(cfg2.__dict__),
+             "param_checksum": np.array([float(v.double().sum()) for v in P2.values()]).sum()}
+    for k, p_ in m2d.named_parameters():
+        g_ = p_.grad if p_.grad is not None else torch.zeros_like(p_)
+        save2[f"gnorm/{k}"] = float(g_.double().norm())
+        save2[f"grad/{k}"] = g_.numpy() if g_.numel() <= 8192 else g_.flatten()[::7].numpy()
+    np.savez_compressed(os.path.join(out_dir, "mae2d_small.npz"), **save2)
+    print("2-D MAE: loss", float(loss2), "pred", tuple(pred2.shape))
+    os.chdir(REF)
 
     # ------------------------------------------------------------------ ViT-L scalar pins
     if not args.skip_vitl:

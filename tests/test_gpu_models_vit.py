@@ -1,0 +1,111 @@
+"""GPU parity of the two other §8 models against golden vectors produced by the real reference:
+  R11  spatio-temporal fine-tune ViT (OCTCube/models_vit_st_flash_attn.py, non-flash blocks)
+  R2   2-D MAE (OCTCube/models_mae.py; timm 0.3.2 blocks, BASELINE config 1)
+Tolerances as in test_gpu_model.py (bf16 operands): logits / pred rel-L2 <= 1e-2, loss rel <= 2e-3, gradients rel-L2 <= 5e-2."""
+import json
+import os
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from octcubem_amd import models_vit_st, models_mae_2d
+from oracle import vit_ref as V
+
+DEV = "cuda"
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().flatten().cpu(); b = torch.as_tensor(b).detach().double().flatten().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def check_grads(model, z, tol=5e-2):
+    total = float(np.sqrt(sum(float(z[k]) ** 2 for k in z.files if k.startswith("gnorm/"))))
+    for k, p in model.named_parameters():
+        if f"gnorm/{k}" not in z.files:
+            continue
+        gn = float(z[f"gnorm/{k}"])
+        g = p.grad
+        if gn < 1e-6 * total:
+            assert g is None or float(g.double().norm()) <= 1e-4 * total, k
+            continue
+        ref = torch.from_numpy(z[f"grad/{k}"])
+        mine = g.cpu() if g.numel() <= 8192 else g.cpu().flatten()[::7]
+        assert rel(mine.reshape(ref.shape), ref) <= tol, (k, rel(mine.reshape(ref.shape), ref))
+
+
+def test_vit_st_vs_reference_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "vit_st_small.npz"))
+    cfg = V.ViTSTConfig(**json.loads(str(z["cfg"])))
+    P = V.init_from_shapes(V.vit_st_param_shapes(cfg), seed=int(z["param_seed"]))
+    kw = dict(num_frames=cfg.num_frames, t_patch_size=cfg.t_patch_size, img_size=cfg.img_size, patch_size=cfg.patch_size,
+              in_chans=cfg.in_chans, num_classes=cfg.num_classes, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
+              mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), sep_pos_embed=True, cls_embed=True)
+    m = models_vit_st.VisionTransformer(global_pool=True, **kw)
+    assert set(m.state_dict()) == set(P)
+    m.load_state_dict(P, strict=True)
+    m = m.to(DEV).eval()
+    x = torch.from_numpy(z["x"]).to(DEV)
+    logits, emb = m(x, return_embeddings=True)
+    assert rel(logits, z["logits"]) <= 1e-2 and rel(emb, z["embedding"]) <= 1e-2
+    loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(z["target"]).to(DEV))
+    # cross-entropy moves by at most 2 x the largest logit error; the logits themselves are held to 1e-2 rel-L2 above
+    dl = float((logits.detach().cpu() - torch.from_numpy(z["logits"])).abs().max())
+    assert abs(float(loss) - float(z["loss"])) <= 2 * dl + 1e-6, (float(loss), float(z["loss"]), dl)
+    assert abs(float(loss) - float(z["loss"])) <= 1e-2 * float(z["loss"])
+    loss.backward()
+    check_grads(m, z)
+    assert m.norm.weight.grad is None or float(m.norm.weight.grad.abs().max()) == 0.0      # computed-but-unused norm
+    m2 = models_vit_st.VisionTransformer(global_pool=False, **kw)
+    m2.load_state_dict(P, strict=True)
+    m2 = m2.to(DEV).eval()
+    with torch.no_grad():
+        assert rel(m2(x), z["logits_cls"]) <= 1e-2
+        hs = m2(x, hidden_states=True)
+    assert len(hs) == cfg.depth and hs[0].shape == (3, 1 + 4 * 16, cfg.embed_dim)
+
+
+def test_mae2d_vs_reference_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "mae2d_small.npz"))
+    cfg = V.MAE2DConfig(**json.loads(str(z["cfg"])))
+    P = V.mae2d_init(cfg, seed=int(z["param_seed"]))
+    m = models_mae_2d.MaskedAutoencoderViT(img_size=cfg.img_size, patch_size=cfg.patch_size, in_chans=cfg.in_chans,
+                                            embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
+                                            decoder_embed_dim=cfg.decoder_embed_dim, decoder_depth=cfg.decoder_depth,
+                                            decoder_num_heads=cfg.decoder_num_heads, mlp_ratio=4,
+                                            norm_layer=partial(torch.nn.LayerNorm, eps=1e-6))
+    assert set(m.state_dict()) == set(P)
+    assert torch.allclose(m.pos_embed, P["pos_embed"]) and torch.allclose(m.decoder_pos_embed, P["decoder_pos_embed"])
+    m.load_state_dict(P, strict=True)
+    m = m.to(DEV)
+    imgs, noise = torch.from_numpy(z["imgs"]).to(DEV), torch.from_numpy(z["noise"]).to(DEV)
+    loss, pred, mask = m(imgs, mask_ratio=0.75, noise=noise)
+    loss.backward()
+    assert torch.equal(mask.cpu(), torch.from_numpy(z["mask"])) and torch.equal(m._ids_restore.cpu(), torch.from_numpy(z["ids_restore"]))
+    assert abs(float(loss) - float(z["loss"])) <= 2e-3 * float(z["loss"])
+    assert rel(pred, z["pred"]) <= 1e-2
+    check_grads(m, z)
+    assert m.pos_embed.grad is None and m.decoder_pos_embed.grad is None            # fixed sin-cos tables
+
+
+def test_config1_vitb_2d_mae_full_size_vs_oracle():
+    """BASELINE config 1: ViT-B MAE forward + loss on 2 x 3 x 256 x 256 random B-scans, HIP path vs the CPU oracle."""
+    cfg = V.MAE2DConfig(img_size=256, embed_dim=768, depth=12, num_heads=12, decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16)
+    P = V.mae2d_init(cfg, seed=3, bias_std=0.0)
+    imgs = torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(0))
+    noise = torch.rand(2, cfg.num_patches, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        loss_r, pred_r, mask_r, ids_r = V.mae2d_forward(P, imgs, cfg, 0.75, noise)
+    m = models_mae_2d.mae_vit_base_patch16(img_size=256)
+    m.load_state_dict(P, strict=True)
+    m = m.to(DEV)
+    with torch.no_grad():
+        loss, pred, mask = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
+    assert torch.equal(mask.cpu(), mask_r) and torch.equal(m._ids_restore.cpu(), ids_r)
+    assert abs(float(loss) - float(loss_r)) <= 1e-3 * float(loss_r)
+    assert rel(pred, pred_r) <= 1e-2

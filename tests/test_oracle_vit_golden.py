@@ -1,0 +1,60 @@
+"""CPU: oracle/vit_ref.py (ST fine-tune ViT, 2-D MAE with timm 0.3.2 blocks) against golden vectors produced by the real
+reference (OCTCube/models_vit_st_flash_attn.py non-flash path, OCTCube/models_mae.py).  Tolerance 1e-5 relative."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import vit_ref as V
+
+
+def relerr(a, b):
+    a = torch.as_tensor(a).double(); b = torch.as_tensor(b).double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_vit_st_forward_backward_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "vit_st_small.npz"))
+    cfg = V.ViTSTConfig(**json.loads(str(z["cfg"])))
+    P = V.init_from_shapes(V.vit_st_param_shapes(cfg), seed=int(z["param_seed"]))
+    assert abs(sum(float(v.double().sum()) for v in P.values()) - float(z["param_checksum"])) < 1e-9
+    x = torch.from_numpy(z["x"])
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    logits, emb = V.vit_st_forward(Pg, x, cfg)
+    assert relerr(logits, z["logits"]) <= 1e-5 and relerr(emb, z["embedding"]) <= 1e-5
+    loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(z["target"]))
+    assert abs(float(loss) - float(z["loss"])) <= 1e-5 * float(z["loss"])
+    loss.backward()
+    for k, v in Pg.items():
+        if f"gnorm/{k}" not in z.files:          # norm.weight / norm.bias: computed-but-unused outcome (:247-249) -> no gradient
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
+            continue
+        ref = torch.from_numpy(z[f"grad/{k}"])
+        mine = v.grad if v.grad.numel() <= 8192 else v.grad.flatten()[::7]
+        if float(z[f"gnorm/{k}"]) > 1e-7:
+            assert relerr(mine.reshape(ref.shape), ref) <= 5e-5, k
+    cfg_cls = V.ViTSTConfig(**{**cfg.__dict__, "global_pool": False})
+    logits_cls, _ = V.vit_st_forward(P, x, cfg_cls)
+    assert relerr(logits_cls, z["logits_cls"]) <= 1e-5
+
+
+def test_mae2d_forward_backward_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "mae2d_small.npz"))
+    cfg = V.MAE2DConfig(**json.loads(str(z["cfg"])))
+    P = V.mae2d_init(cfg, seed=int(z["param_seed"]))
+    assert abs(sum(float(v.double().sum()) for v in P.values()) - float(z["param_checksum"])) < 1e-6
+    imgs, noise = torch.from_numpy(z["imgs"]), torch.from_numpy(z["noise"])
+    loss, pred, mask, ids_restore, grads = V.mae2d_forward_backward(P, imgs, cfg, 0.75, noise)
+    assert torch.equal(ids_restore, torch.from_numpy(z["ids_restore"])) and torch.equal(mask, torch.from_numpy(z["mask"]))
+    assert abs(float(loss) - float(z["loss"])) <= 1e-5 * float(z["loss"])
+    assert relerr(pred, z["pred"]) <= 1e-5
+    for k, g in grads.items():
+        if f"gnorm/{k}" not in z.files:
+            continue
+        gn = float(z[f"gnorm/{k}"])
+        if gn < 1e-7:
+            continue
+        ref = torch.from_numpy(z[f"grad/{k}"])
+        mine = g if g.numel() <= 8192 else g.flatten()[::7]
+        assert relerr(mine.reshape(ref.shape), ref) <= 5e-5, k
