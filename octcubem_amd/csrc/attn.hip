@@ -23,6 +23,9 @@
 
 namespace octmae {
 
+#ifndef ATT_PIPELINE
+#define ATT_PIPELINE(HD) ((HD) == 32)
+#endif
 #ifndef ATT_OCC_FWD32
 #define ATT_OCC_FWD32 3
 #endif
@@ -120,7 +123,7 @@ __device__ __forceinline__ bf16x8 scale_frag(u32x4 v, float s) {
 // forward
 // =====================================================================================================
 template <int HD>
-__global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 2)) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+__global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 3)) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                           float* __restrict__ lse, int N, int H, float scale) {
   constexpr int KS = HD / 16;   // k-steps over the head dimension
   constexpr int DB = HD / 32;   // 32-wide blocks of the head dimension
@@ -225,7 +228,8 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 2)) void attn_fwd_
 #pragma unroll
         for (int g = 0; g < 16; ++g) scur[kb][g] -= d;
     }
-    if (!last) qk(Kbuf + ((t + 1) & 1) * T::BYTES, snext);      // MFMA pipe works on S_{t+1} under the exps below
+    const bool alias = (&scur[0] == &snext[0]);
+    if (!last && !alias) qk(Kbuf + ((t + 1) & 1) * T::BYTES, snext);      // MFMA pipe works on S_{t+1} under the exps below
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -247,6 +251,7 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 2)) void attn_fwd_
         for (int d = 0; d < DB; ++d) oacc[d] = mfma32(T::tr_frag(cV, kb * 32, s, d * 32, lane), pf, oacc[d]);
         if (ONES_SUM) lacc = mfma32(ones, pf, lacc);
       }
+    if (!last && alias) qk(Kbuf + ((t + 1) & 1) * T::BYTES, snext);
     // staging for the tiles ahead
     if (t + 1 < ntiles) {
       sv.commit(Vbuf + ((t + 1) & 1) * T::BYTES, tid);
@@ -262,15 +267,22 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 2)) void attn_fwd_
   f32x16 sA[2], sB[2];
   qk(Kbuf, sA);
   int t = 0;
-  for (; t + 2 < ntiles; t += 2) {
-    step(t, sA, sB, std::false_type{});
-    step(t + 1, sB, sA, std::false_type{});
-  }
-  if (t + 1 < ntiles) {
-    step(t, sA, sB, std::false_type{});
-    step(t + 1, sB, sA, std::true_type{});
+  if (ATT_PIPELINE(HD)) {
+    for (; t + 2 < ntiles; t += 2) {
+      step(t, sA, sB, std::false_type{});
+      step(t + 1, sB, sA, std::false_type{});
+    }
+    if (t + 1 < ntiles) {
+      step(t, sA, sB, std::false_type{});
+      step(t + 1, sB, sA, std::true_type{});
+    } else {
+      step(t, sA, sB, std::true_type{});
+    }
   } else {
-    step(t, sA, sB, std::true_type{});
+    // same data flow without keeping two score tiles live (32 fewer VGPRs -> one more wave per SIMD): S_{t+1} is still
+    // issued before tile t's exps, but into the SAME registers after P_t has been packed -- i.e. after the PV MFMAs
+    for (; t + 1 < ntiles; ++t) step(t, sA, sA, std::false_type{});
+    step(t, sA, sA, std::true_type{});
   }
 
   // every row of the ones-MFMA accumulator holds the full row sum (both lane halves); the VALU form is per half
