@@ -234,3 +234,41 @@ def test_full_size_properties_batch2():
     with torch.no_grad():
         l1, p1, _ = m(imgs[1:], mask_ratio=0.75, noise=noise[1:])
     assert rel(p1, pred[1:].detach()) <= 1e-6
+
+
+def test_fused_block_backward_with_shared_activation():
+    """BlockFn hands the bf16 copy / column sums of its input gradient to the upstream Block through a side channel that
+    is only valid when autograd delivers that very tensor.  Here the first Block's output feeds BOTH the second Block and
+    the loss, so autograd sums two contributions into a new tensor and the side channel must be ignored (work redone
+    locally, nothing double counted).  Checked against the oracle's blocks."""
+    from octcubem_amd import video_vit
+    from functools import partial
+    D, H, B, N = 128, 2, 2, 70
+    g = torch.Generator().manual_seed(0)
+    blocks = [video_vit.Block(D, H, 4.0, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6)) for _ in range(2)]
+    P = {}
+    for i, blk in enumerate(blocks):
+        for n_, p_ in blk.named_parameters():
+            with torch.no_grad():
+                p_.copy_(torch.randn(p_.shape, generator=g) * (0.05 if p_.dim() > 1 else 0.02) + (1.0 if "norm" in n_ and n_.endswith("weight") else 0.0))
+            P[f"blocks.{i}.{n_}"] = p_.detach().clone()
+    model = torch.nn.ModuleList(blocks).to(DEV)
+    x = torch.randn(B, N, D, generator=g)
+    w1 = torch.randn(B, N, D, generator=g); w2 = torch.randn(B, N, D, generator=g)
+    xg = x.to(DEV).requires_grad_(True)
+    h1 = model[0](xg)
+    h2 = model[1](h1)
+    loss = (h2 * w2.to(DEV)).sum() + (h1 * w1.to(DEV)).sum()          # h1 is used twice
+    loss.backward()
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xr = x.clone().requires_grad_(True)
+    r1 = O.block(xr, Pr, "blocks.0", H, 1e-6)
+    r2 = O.block(r1, Pr, "blocks.1", H, 1e-6)
+    ((r2 * w2).sum() + (r1 * w1).sum()).backward()
+    assert rel(xg.grad, xr.grad) <= 3e-2
+    for i, blk in enumerate(model):
+        for n_, p_ in blk.named_parameters():
+            ref = Pr[f"blocks.{i}.{n_}"].grad
+            if float(ref.norm()) < 1e-6 * float(xr.grad.norm()):
+                continue
+            assert rel(p_.grad, ref) <= 5e-2, (i, n_, rel(p_.grad, ref))
