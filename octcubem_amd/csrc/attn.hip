@@ -182,11 +182,13 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 3)) void attn_fwd_
   __syncthreads();
 
   auto qk = [&](const char* cK, f32x16 (&sa)[2]) {
+    // row constant -m_s as the initial accumulator (a persistent 16-register tile of it would save the broadcast but
+    // pushes the kernel past the 168-VGPR budget of 3 waves per SIMD: measured 2.4x slower from spills)
     const float neg_m = -m_s;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int g = 0; g < 16; ++g) sa[kb][g] = neg_m;          // row constant as the initial accumulator
+      for (int g = 0; g < 16; ++g) sa[kb][g] = neg_m;
 #pragma unroll
       for (int s = 0; s < KS; ++s) sa[kb] = mfma32(T::row_frag(cK, kb * 32, s, lane), qf[s], sa[kb]);
     }
@@ -372,11 +374,13 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DQ32 : 2)) void attn_bwd_d
     dlt = delta[((size_t)b * H + head) * N + qrow];
   }
 
-  f32x16 dq[DB];
+  f32x16 dq[DB], lse_t, dlt_t;   // row constants replicated over an accumulator tile: out-of-place C operands, set once
 #pragma unroll
   for (int d = 0; d < DB; ++d)
 #pragma unroll
     for (int g = 0; g < 16; ++g) dq[d][g] = 0.f;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) { lse_t[g] = -lse2; dlt_t[g] = -dlt; }
 
   const int ntiles = (N + 63) / 64;
   TileStage<HD> sk, sv;
@@ -397,12 +401,12 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DQ32 : 2)) void attn_bwd_d
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 sa, dp;
+      sa = mfma32(T::row_frag(cK, kb * 32, 0, lane), qf[0], lse_t);     // row constants as the initial accumulators
 #pragma unroll
-      for (int g = 0; g < 16; ++g) { sa[g] = -lse2; dp[g] = -dlt; }   // row constants as the initial accumulators
+      for (int s = 1; s < KS; ++s) sa = mfma32(T::row_frag(cK, kb * 32, s, lane), qf[s], sa);
+      dp = mfma32(T::row_frag(cV, kb * 32, 0, lane), dof[0], dlt_t);
 #pragma unroll
-      for (int s = 0; s < KS; ++s) sa = mfma32(T::row_frag(cK, kb * 32, s, lane), qf[s], sa);
-#pragma unroll
-      for (int s = 0; s < KS; ++s) dp = mfma32(T::row_frag(cV, kb * 32, s, lane), dof[s], dp);
+      for (int s = 1; s < KS; ++s) dp = mfma32(T::row_frag(cV, kb * 32, s, lane), dof[s], dp);
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         float p = fast_exp2(sa[g]);
