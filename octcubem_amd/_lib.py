@@ -20,7 +20,7 @@ SIGNATURES = {
     "octmae_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "octmae_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "octmae_layernorm_bwd_ws_floats": [_i, _i],
-    "octmae_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "octmae_attn_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "octmae_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "octmae_attn_bwd_delta": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "octmae_attn_bwd_dq": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],

@@ -122,9 +122,18 @@ __device__ __forceinline__ bf16x8 scale_frag(u32x4 v, float s) {
 // =====================================================================================================
 // forward
 // =====================================================================================================
-template <int HD>
+// FAST = optimistic variant: no running max at all (reference point 0 in the scaled log2 domain).  Floating point is
+// scale-free, so exp2(s) / sum exp2(s) is exactly as accurate as the max-subtracted form as long as nothing overflows
+// (s*scale*log2e > 127) or a whole row underflows; pre-norm ViT logits are nowhere near that.  The kernel checks every
+// row sum at the end and raises `*flag` if one is not a finite positive number; the host ALWAYS enqueues the safe
+// (online-max) kernel right after, which returns immediately unless the flag is set and otherwise recomputes everything.
+// No host synchronisation, and the result is always the safe one when it matters.  What the fast variant saves is VALU
+// work, the limiter of this kernel: no max chain, no rescale, and the score accumulators start from the inline constant 0
+// (no per-tile broadcast of -max): per score only v_exp_f32 + v_cvt_pk remain.
+template <int HD, bool FAST>
 __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 3)) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
-                                                          float* __restrict__ lse, int N, int H, float scale) {
+                                                          float* __restrict__ lse, int N, int H, float scale, int* __restrict__ flag) {
+  if (!FAST && flag != nullptr && *flag == 0) return;   // safe kernel: only runs when the optimistic one gave up
   constexpr int KS = HD / 16;   // k-steps over the head dimension
   constexpr int DB = HD / 32;   // 32-wide blocks of the head dimension
   using T = Tile<HD>;
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 3)) void attn_fwd_
   auto qk = [&](const char* cK, f32x16 (&sa)[2]) {
     // row constant -m_s as the initial accumulator (a persistent 16-register tile of it would save the broadcast but
     // pushes the kernel past the 168-VGPR budget of 3 waves per SIMD: measured 2.4x slower from spills)
-    const float neg_m = -m_s;
+    const float neg_m = FAST ? 0.f : -m_s;                      // FAST: literal 0 -> the MFMA's inline-constant C operand
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -207,28 +216,30 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 3)) void attn_fwd_
           if (key >= N) scur[kb][g] = -INFINITY;
         }
     }
-    // excess of this tile's scores over the running max (two chains for ILP)
-    float e0 = scur[0][0], e1 = scur[1][0];
+    if (!FAST) {
+      // excess of this tile's scores over the running max (two chains for ILP)
+      float e0 = scur[0][0], e1 = scur[1][0];
 #pragma unroll
-    for (int g = 1; g < 16; ++g) { e0 = fmaxf(e0, scur[0][g]); e1 = fmaxf(e1, scur[1][g]); }
-    float ex = fmaxf(e0, e1);
-    ex = fmaxf(ex, __shfl_xor(ex, 32, 64));
-    // Deferred rescale (wave-uniform, rare after the first tiles): decided BEFORE this tile's P is formed, so everything
-    // accumulated so far is at the old max and is scaled exactly once; the pending scores are shifted by the same amount.
-    if (t == 0 || !__all(ex <= RESCALE_SLACK)) {
-      const float d = (t == 0) ? ex : fmaxf(ex, 0.f);
-      const float alpha = fast_exp2(-d);
-      m_s += d;
-      l_run *= alpha;
-      lacc[0] *= alpha;
+      for (int g = 1; g < 16; ++g) { e0 = fmaxf(e0, scur[0][g]); e1 = fmaxf(e1, scur[1][g]); }
+      float ex = fmaxf(e0, e1);
+      ex = fmaxf(ex, __shfl_xor(ex, 32, 64));
+      // Deferred rescale (wave-uniform, rare after the first tiles): decided BEFORE this tile's P is formed, so everything
+      // accumulated so far is at the old max and is scaled exactly once; the pending scores are shifted by the same amount.
+      if (t == 0 || !__all(ex <= RESCALE_SLACK)) {
+        const float d = (t == 0) ? ex : fmaxf(ex, 0.f);
+        const float alpha = (t == 0) ? 1.f : fast_exp2(-d);   // t == 0: nothing accumulated yet (and d may be hugely negative)
+        m_s += d;
+        l_run *= alpha;
+        lacc[0] *= alpha;
 #pragma unroll
-      for (int dd = 0; dd < DB; ++dd)
+        for (int dd = 0; dd < DB; ++dd)
 #pragma unroll
-        for (int g = 0; g < 16; ++g) oacc[dd][g] *= alpha;
+          for (int g = 0; g < 16; ++g) oacc[dd][g] *= alpha;
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int g = 0; g < 16; ++g) scur[kb][g] -= d;
+          for (int g = 0; g < 16; ++g) scur[kb][g] -= d;
+      }
     }
     const bool alias = (&scur[0] == &snext[0]);
     if (!last && !alias) qk(Kbuf + ((t + 1) & 1) * T::BYTES, snext);      // MFMA pipe works on S_{t+1} under the exps below
@@ -290,6 +301,10 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 3)) void attn_fwd_
   // every row of the ones-MFMA accumulator holds the full row sum (both lane halves); the VALU form is per half
   const float l_tot = ONES_SUM ? lacc[0] : (l_run + __shfl_xor(l_run, 32, 64));
   const float inv = 1.0f / l_tot;
+  if (FAST) {
+    const bool bad = (qrow < N) && !(l_tot > 0.f && l_tot < 3.0e38f);      // inf, NaN or 0: overflow / whole-row underflow
+    if (__any(bad) && lane == 0) atomicOr(flag, 1);
+  }
   if (qrow < N) {
     bf16_t* orow = o + ((size_t)b * N + qrow) * (size_t)(H * HD) + (size_t)head * HD;
 #pragma unroll
@@ -595,10 +610,16 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DKV32 : 2)) void attn_bwd_
 }
 
 template <int HD>
-static int run_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, int H, float scale, hipStream_t st) {
+static int run_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, int H, float scale, int* flag, hipStream_t st) {
   const int lds = 4 * Tile<HD>::BYTES;
   dim3 grid((N + 127) / 128, H, B);
-  hipLaunchKernelGGL(attn_fwd_kernel<HD>, grid, dim3(256), lds, st, qkv, o, lse, N, H, scale);
+  if (flag != nullptr) {      // optimistic kernel, then the safe one (a no-op unless the flag was raised)
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(256), lds, st, qkv, o, lse, N, H, scale, flag);
+    OCTMAE_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL((attn_fwd_kernel<HD, false>), grid, dim3(256), lds, st, qkv, o, lse, N, H, scale, flag);
   OCTMAE_LAUNCH_CHECK();
   return 0;
 }
@@ -632,12 +653,13 @@ static int run_dkv(const bf16_t* qkv, const bf16_t* dout, const float* lse, cons
 }  // namespace octmae
 using namespace octmae;
 
-extern "C" int octmae_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int HD, float scale, void* stream) {
+extern "C" int octmae_attn_fwd(const void* qkv, void* o, float* lse, int* flag_ws, int B, int N, int H, int HD, float scale,
+                               void* stream) {
   OCTMAE_CHECK_ARG(qkv && o && lse && B > 0 && N > 0 && H > 0);
   OCTMAE_CHECK_ARG(HD == 64 || HD == 32);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (HD == 64) return run_fwd<64>(reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<bf16_t*>(o), lse, B, N, H, scale, st);
-  return run_fwd<32>(reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<bf16_t*>(o), lse, B, N, H, scale, st);
+  if (HD == 64) return run_fwd<64>(reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<bf16_t*>(o), lse, B, N, H, scale, flag_ws, st);
+  return run_fwd<32>(reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<bf16_t*>(o), lse, B, N, H, scale, flag_ws, st);
 }
 
 #define BFP(x) reinterpret_cast<const bf16_t*>(x)

@@ -218,11 +218,16 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None, want_bf16=
     return dx, dxb
 
 
-def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, HD: int, scale: float):
+ATTN_OPTIMISTIC = True    # optimistic (no running max) forward first, safe kernel as the device-side fallback
+
+
+def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, HD: int, scale: float, optimistic: Optional[bool] = None):
     o = torch.empty((B * N, H * HD), dtype=BF16, device=qkv.device)
     lse = torch.empty((B, H, N), dtype=F32, device=qkv.device)
+    opt = ATTN_OPTIMISTIC if optimistic is None else optimistic
+    flag = torch.empty((1,), dtype=torch.int32, device=qkv.device) if opt else None
     _launch(f"attn_fwd_hd{HD}", 4.0 * B * H * N * N * HD, 2.0 * 4 * B * N * H * HD,
-            lambda: call("octmae_attn_fwd", qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, HD, float(scale), _stream()))
+            lambda: call("octmae_attn_fwd", qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), _p(flag), B, N, H, HD, float(scale), _stream()))
     return o, lse
 
 

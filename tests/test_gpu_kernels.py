@@ -190,14 +190,15 @@ def attn_ref(qkv, B, N, H, HD):
     return (p @ v).transpose(1, 2).reshape(B * N, H * HD), torch.logsumexp(s, -1)
 
 
+@pytest.mark.parametrize("optimistic", [True, False])
 @pytest.mark.parametrize("HD", [64, 32])
 @pytest.mark.parametrize("N", [1, 31, 64, 65, 129, 200, 1281])
-def test_attention_fwd_bwd(HD, N):
+def test_attention_fwd_bwd(HD, N, optimistic):
     B, H = 2, 3
     g = torch.Generator().manual_seed(N * 3 + HD)
     qkv = bf(torch.randn(B * N, 3 * H * HD, generator=g)).to(DEV)
     do = bf(torch.randn(B * N, H * HD, generator=g)).to(DEV)
-    o, lse = ops.attn_fwd(qkv, B, N, H, HD, HD ** -0.5)
+    o, lse = ops.attn_fwd(qkv, B, N, H, HD, HD ** -0.5, optimistic=optimistic)
     qd = qkv.double().requires_grad_(True)
     o_ref, lse_ref = attn_ref(qd, B, N, H, HD)
     assert rel(o, o_ref) < 4e-3                                   # bf16 P and bf16 output
@@ -210,7 +211,10 @@ def test_attention_fwd_bwd(HD, N):
     scale_ref = float(ref.norm()) / ref.numel() ** 0.5
     for i, name in enumerate("qkv"):
         if float(ref[:, :, i].norm()) < 1e-9:                     # N == 1: dq = dk = 0 exactly in exact arithmetic
-            assert float(got[:, :, i].abs().max()) < 1e-5 * max(scale_ref, 1.0), name
+            # with max subtraction P == 1 exactly; the optimistic forward normalises a bf16-rounded P by its fp32 value
+            # (head_dim 64), which leaves the usual 2^-9 rounding noise in o and hence in dS
+            tol = 1e-5 if not optimistic else 2e-2
+            assert float(got[:, :, i].abs().max()) < tol * max(scale_ref, 1.0), name
         else:
             assert rel(got[:, :, i], ref[:, :, i]) < 1.5e-2, name     # bf16 P, dS and outputs
 
@@ -224,7 +228,7 @@ def test_attention_online_softmax_rescale_branch(HD):
     x[17, 0, 0] *= 8.0
     x[257, 1, 0] = x[17, 0, 0]            # key 257 (5th tile) aligned with query 17
     qkv = bf(x.reshape(B * N, -1)).to(DEV)
-    o, lse = ops.attn_fwd(qkv, B, N, H, HD, HD ** -0.5)
+    o, lse = ops.attn_fwd(qkv, B, N, H, HD, HD ** -0.5, optimistic=False)
     o_ref, lse_ref = attn_ref(qkv, B, N, H, HD)
     assert torch.isfinite(o).all()
     assert rel(o, o_ref) < 5e-3 and float((lse.double() - lse_ref).abs().max()) < 4e-3 * (1.0 + float(lse_ref.abs().max()))
@@ -328,3 +332,25 @@ def test_fused_adamw_and_grad_norm_match_oracle(golden_dir):
     # clip coefficient folded into the step
     norm, coef = foptim.grad_norm_and_coef(ps, 0.5, {})
     assert abs(float(coef) - min(1.0, 0.5 / (float(norm) + 1e-6))) < 1e-6
+
+
+@pytest.mark.parametrize("HD", [64, 32])
+@pytest.mark.parametrize("kind", ["overflow", "underflow"])
+def test_attention_optimistic_forward_falls_back(HD, kind):
+    """The optimistic forward (no running max) must hand over to the online-max kernel when a score leaves exp2's range:
+    logits of +-400 (natural units) in one row -> overflow / whole-row underflow without max subtraction."""
+    B, H, N = 1, 2, 200
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B * N, 3, H, HD, generator=g)
+    big = (400.0 * HD ** 0.5) ** 0.5
+    x[5, 0, 1] = big / HD ** 0.5                         # query 5 of head 1 ...
+    x[:, 1, 1] = (-1.0 if kind == "underflow" else 0.0) * big / HD ** 0.5 + 0.01 * x[:, 1, 1]
+    if kind == "overflow":
+        x[77, 1, 1] = big / HD ** 0.5                    # ... meets key 77: q.k*scale = +400
+    qkv = bf(x.reshape(B * N, -1)).to(DEV)
+    o, lse = ops.attn_fwd(qkv, B, N, H, HD, HD ** -0.5, optimistic=True)
+    o_safe, lse_safe = ops.attn_fwd(qkv, B, N, H, HD, HD ** -0.5, optimistic=False)
+    o_ref, lse_ref = attn_ref(qkv, B, N, H, HD)
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    assert torch.equal(o, o_safe) and torch.equal(lse, lse_safe)          # the fallback recomputed everything
+    assert rel(o, o_ref) < 6e-3
