@@ -35,7 +35,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     lib = _lib.load()
     # NULL pointers / bad sizes are rejected before any launch
     assert lib.octmae_gemm_bf16(None, None, None, None, None, None, 8, 8, 8, 8, 8, 8, 0, 0, 0, 0, 1, None) == -1
-    assert lib.octmae_attn_fwd(None, None, None, 1, 1, 1, 64, 0.125, None) == -1
+    assert lib.octmae_attn_fwd(None, None, None, None, 1, 1, 1, 64, 0.125, None) == -1
     assert lib.octmae_layernorm_fwd(None, None, None, None, None, None, 1, 64, 1e-6, None) == -1
     assert lib.octmae_random_masking_ids(None, None, None, None, None, 1, 8, 2, None) == -1
     with pytest.raises(_lib.OctmaeError):
@@ -133,3 +133,41 @@ def test_arena_ordering_makes_qkv_adjacent():
     out = [n for n, _ in _ordered([(n, None) for n in names])]
     assert out == ["a.norm1.weight", "a.attn.q.weight", "a.attn.k.weight", "a.attn.v.weight", "a.attn.q.bias", "a.attn.k.bias",
                    "a.attn.v.bias", "a.attn.proj.weight", "a.attn.proj.bias"]
+
+
+def test_lr_decay_groups_match_reference_golden(golden_dir):
+    """octcubem_amd.lr_decay on a parameter-only stand-in for the ST ViT (no GPU) vs the groups the reference built."""
+    import json
+    import numpy as np
+    import torch
+    from octcubem_amd import lr_decay
+    from oracle import vit_ref as V
+    z = np.load(os.path.join(golden_dir, "finetune_small.npz"))
+    cfg = V.ViTSTConfig(**json.loads(str(z["cfg"])))
+    shapes = V.vit_st_param_shapes(cfg)
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blocks = [None] * cfg.depth
+            self._names = {}
+            for n, s in shapes.items():
+                key = n.replace(".", "__")
+                self.register_parameter(key, torch.nn.Parameter(torch.zeros(s)))
+                self._names[key] = n
+
+        def named_parameters(self, *a, **k):
+            for key, p in super().named_parameters(*a, **k):
+                yield self._names[key], p
+    m = Stub()
+    groups = lr_decay.param_groups_lrd(m, 0.05, no_weight_decay_list=("cls_token", "pos_embed", "pos_embed_spatial",
+                                                                    "pos_embed_temporal", "pos_embed_class"), layer_decay=0.75)
+    id2name = {id(p): n for n, p in m.named_parameters()}
+    ref = json.loads(str(z["groups"]))
+    key = lambda g: (g["lr_scale"], g["weight_decay"])
+    assert len(groups) == len(ref)
+    for a, b in zip(sorted(groups, key=key), sorted(ref, key=key)):
+        assert sorted(id2name[id(p)] for p in a["params"]) == sorted(b["params"])
+        assert a["weight_decay"] == b["weight_decay"] and abs(a["lr_scale"] - b["lr_scale"]) < 1e-15
+    for n, lid in json.loads(str(z["layer_ids"])).items():
+        assert lr_decay.get_layer_id_for_vit(n, cfg.depth + 1) == lid

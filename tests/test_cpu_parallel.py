@@ -73,6 +73,8 @@ def _worker(rank, world, port, q):
     loss.backward()
     red.finish()
     out["grad_hook"] = arena.grad.clone()
+    # by value (numpy), not as shared-memory handles: a handle needs this process alive when the parent unpickles it
+    out = {k: (v.numpy() if isinstance(v, torch.Tensor) else [t.numpy() for t in v] if k == "local" else v) for k, v in out.items()}
     q.put(out)
     dist.barrier()
     dist.destroy_process_group()
@@ -87,6 +89,8 @@ def test_flat_grad_reducer_gloo_world2():
     for p in procs:
         p.start()
     outs = sorted([q.get(timeout=100) for _ in range(2)], key=lambda o: o["rank"])
+    outs = [{k: (torch.from_numpy(v) if hasattr(v, "dtype") else [torch.from_numpy(t) for t in v] if k == "local" else v)
+             for k, v in o.items()} for o in outs]
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
