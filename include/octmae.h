@@ -38,6 +38,13 @@ int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2, const floa
                      int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided, int b_kstrided,
                      int epilogue, int splitk, void* stream);
 
+/* Stochastic depth (timm DropPath around both Block branches, video_vit.py:181-184 with drop_path > 0; fine-tune drivers use
+ * 0.1-0.2): out f32 [M][N] = res + rowscale[m / rows_per_scale] * (X[M][K] @ W[N][K]^T + bias) -- the per-sample keep mask
+ * (0 or 1/keep_prob) applied to the branch inside the residual epilogue.  nn.Linear layouts; small_tile as bit 8 above. */
+int octmae_linear_resid_rowscale(const void* W, const void* X, float* out, const float* bias, const float* res,
+                                 const float* rowscale, int rows_per_scale, int N, int M, int K, int ldw, int ldx, int ldout,
+                                 int ldres, int small_tile, void* stream);
+
 /* ---- LayerNorm over the fp32 residual stream ---------------------------------------------------
  * nn.LayerNorm(eps=1e-6): models_mae_joint_res_flash_attn.py:799, video_vit.py:161,172,181-184, :489, :592.
  * fwd: y bf16 = (x - mean) * rstd * gamma + beta; saves mean, rstd (fp32 [M]).
@@ -79,6 +86,9 @@ int octmae_random_masking_ids(const float* noise, long long* ids_restore, long l
 
 /* ---- token plumbing ------------------------------------------------------------------------------ */
 int octmae_cast_f32_bf16(const float* src, void* dst_bf16, long long n, void* stream);
+/* dst bf16 [R][D] = rowscale[r / rows_per_scale] * src f32 [R][D]: the gradient entering a stochastic-depth branch */
+int octmae_cast_rowscale_f32_bf16(const float* src, const float* rowscale, void* dst_bf16, long long R, int D,
+                                  int rows_per_scale, void* stream);
 /* out[c] += sum_r in[r][c]  (nn.Linear bias gradient) */
 int octmae_colsum_accum(const void* in, int in_is_bf16, float* out, int M, int N, int ld, void* stream);
 /* im2col of the kept tokens for PatchEmbed's Conv3d(k = s = (tp,p,p)), video_vit.py:70-83 + the gather at

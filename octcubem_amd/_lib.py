@@ -27,6 +27,8 @@ SIGNATURES = {
     "octmae_attn_bwd_dkv": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "octmae_random_masking_ids": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "octmae_cast_f32_bf16": [_vp, _vp, _ll, _vp],
+    "octmae_cast_rowscale_f32_bf16": [_vp, _vp, _vp, _ll, _i, _i, _vp],
+    "octmae_linear_resid_rowscale": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "octmae_colsum_accum": [_vp, _i, _vp, _i, _i, _i, _vp],
     "octmae_patch_gather": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "octmae_enc_assemble": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

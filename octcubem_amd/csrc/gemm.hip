@@ -44,6 +44,8 @@ struct GemmParams {
   int lda, ldb, ldc, ldaux;
   int tiles_a, tiles_b;
   int ktiles, ktiles_per_split;
+  const float* rowscale;   // EPI_RESID only: C = aux + rowscale[b / rows_per_scale] * (X + bias)   (stochastic depth); NULL = 1
+  int rows_per_scale;
 };
 
 // ---- LDS images ------------------------------------------------------------------------------
@@ -151,7 +153,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C2) + o) = w2;
           } else if (EPI == EPI_RESID) {
             const f32x4 rv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.aux) + (size_t)b * p.ldaux + a);
-            f32x4 w = {v[0] + rv[0], v[1] + rv[1], v[2] + rv[2], v[3] + rv[3]};
+            const float sc = p.rowscale ? p.rowscale[b / p.rows_per_scale] : 1.0f;
+            f32x4 w = {sc * v[0] + rv[0], sc * v[1] + rv[1], sc * v[2] + rv[2], sc * v[3] + rv[3]};
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + o) = w;
           } else if (EPI == EPI_DGELU) {
             const u32x2 pre = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.aux) + (size_t)b * p.ldaux + a);
@@ -393,6 +396,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)b * p.ldc + a) = v;
           } else if (EPI == EPI_RESID) {
             const f32x4 rv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.aux) + (size_t)b * p.ldaux + a);
+            if (p.rowscale) v = v * p.rowscale[b / p.rows_per_scale];
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)b * p.ldc + a) = v + rv;
           }
         }
@@ -500,9 +504,9 @@ static int launch(const GemmParams& p, int splitk, hipStream_t st) {
 using namespace octmae;
 
 // C[b][a] (+epilogue) = sum_k A[a][k] B[b][k];  see include/octmae.h for the contract.
-extern "C" int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
-                                int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided,
-                                int b_kstrided, int epilogue, int splitk, void* stream) {
+static int gemm_impl(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
+                     int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided,
+                     int b_kstrided, int epilogue, int splitk, void* stream, const float* rowscale, int rows_per_scale) {
   // bit 8 of `epilogue` forces the 128-tile kernel (tests exercise both tile shapes on the same problem)
   const int variant = (epilogue >> 8) & 1;
   epilogue &= 0xff;
@@ -522,6 +526,7 @@ extern "C" int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2,
   p.A = reinterpret_cast<const bf16_t*>(A);
   p.B = reinterpret_cast<const bf16_t*>(B);
   p.C = C; p.C2 = C2; p.bias = bias; p.aux = aux;
+  p.rowscale = rowscale; p.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
   p.NA = NA; p.NB = NB; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
   p.ktiles = (K + TK - 1) / TK;
@@ -555,4 +560,19 @@ extern "C" int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2,
   OCTMAE_GEMM_CASE(1, 1, EPI_ACCUM, true)
 #undef OCTMAE_GEMM_CASE
   return -2;  // layout / epilogue combination not built
+}
+
+extern "C" int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
+                                int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided,
+                                int b_kstrided, int epilogue, int splitk, void* stream) {
+  return gemm_impl(A, B, C, C2, bias, aux, NA, NB, K, lda, ldb, ldc, ldaux, a_kstrided, b_kstrided, epilogue, splitk, stream,
+                   nullptr, 1);
+}
+
+extern "C" int octmae_linear_resid_rowscale(const void* W, const void* X, float* out, const float* bias, const float* res,
+                                            const float* rowscale, int rows_per_scale, int N, int M, int K, int ldw, int ldx,
+                                            int ldout, int ldres, int small_tile, void* stream) {
+  OCTMAE_CHECK_ARG(rowscale != nullptr && rows_per_scale > 0);
+  return gemm_impl(W, X, out, nullptr, bias, res, N, M, K, ldw, ldx, ldout, ldres, 0, 0, EPI_RESID | (small_tile ? 0x100 : 0), 1,
+                   stream, rowscale, rows_per_scale);
 }

@@ -23,6 +23,20 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
   }
 }
 
+// dst bf16 [R][D] = rowscale[r / rows_per_scale] * src f32 [R][D]   (stochastic-depth backward: the branch gradient)
+__global__ __launch_bounds__(256) void cast_rowscale_kernel(const float* __restrict__ src, const float* __restrict__ rowscale,
+                                                            bf16_t* __restrict__ dst, size_t R, int D, int rows_per_scale) {
+  const int d8 = D >> 3;
+  const size_t n8 = R * (size_t)d8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const float sc = rowscale[(i / d8) / rows_per_scale];
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + 8 * i) * sc;
+    const f32x4 b = *reinterpret_cast<const f32x4*>(src + 8 * i + 4) * sc;
+    u32x4 w = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+    *reinterpret_cast<u32x4*>(dst + 8 * i) = w;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // out[c] += sum_rows in[r][c]   (bias gradients).  Block = 32 row-lanes x 8 column-lanes of 8 columns.
 template <bool IN_BF16>
@@ -304,6 +318,16 @@ extern "C" int octmae_cast_f32_bf16(const float* src, void* dst_bf16, long long 
   if (n == 0) return 0;
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for((size_t)n / 8 + 1)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), src, reinterpret_cast<bf16_t*>(dst_bf16), (size_t)n);
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int octmae_cast_rowscale_f32_bf16(const float* src, const float* rowscale, void* dst_bf16, long long R, int D,
+                                             int rows_per_scale, void* stream) {
+  OCTMAE_CHECK_ARG(src && rowscale && dst_bf16 && R >= 0 && D > 0 && D % 8 == 0 && rows_per_scale > 0);
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(cast_rowscale_kernel, dim3(grid_for((size_t)R * (D / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     src, rowscale, reinterpret_cast<bf16_t*>(dst_bf16), (size_t)R, D, rows_per_scale);
   OCTMAE_LAUNCH_CHECK();
   return 0;
 }

@@ -113,6 +113,16 @@ def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def cast_bf16_rowscale(x2d: torch.Tensor, rowscale: torch.Tensor, rows_per_scale: int) -> torch.Tensor:
+    """bf16(rowscale[r // rows_per_scale] * x2d[r]) for fp32 x2d [R, D] (the gradient entering a stochastic-depth branch)."""
+    _chk(x2d, F32, "cast_bf16_rowscale"); _chk(rowscale, F32, "rowscale")
+    R, D = x2d.shape
+    assert rowscale.numel() * rows_per_scale == R
+    out = torch.empty((R, D), dtype=BF16, device=x2d.device)
+    call("octmae_cast_rowscale_f32_bf16", x2d.data_ptr(), rowscale.data_ptr(), out.data_ptr(), R, D, rows_per_scale, _stream())
+    return out
+
+
 def cast_bf16_into(src: torch.Tensor, dst: torch.Tensor):
     call("octmae_cast_f32_bf16", src.data_ptr(), dst.data_ptr(), src.numel(), _stream())
 
@@ -141,12 +151,20 @@ def _gemm(A, B, C, NA, NB, K, lda, ldb, ldc, a_ks, b_ks, epi, C2=None, bias=None
 
 
 def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mode: str = "bf16",
-               res: Optional[torch.Tensor] = None):
+               res: Optional[torch.Tensor] = None, rowscale: Optional[torch.Tensor] = None, rows_per_scale: int = 1):
     """y = x @ w.T + bias.  x bf16 [M,K], w bf16 [N,K], bias f32 [N].
-    mode: 'bf16' | 'f32' | 'gelu' (returns (pre, act)) | 'resid' (f32: res + y)."""
+    mode: 'bf16' | 'f32' | 'gelu' (returns (pre, act)) | 'resid' (f32: res + y, or res + rowscale[m // rows_per_scale] * y)."""
     M, K = x.shape
     N = w.shape[0]
     dev = x.device
+    if rowscale is not None:
+        assert mode == "resid" and rowscale.dtype == F32 and rowscale.numel() * rows_per_scale == M
+        out = torch.empty((M, N), dtype=F32, device=dev)
+        args = (w.data_ptr(), x.data_ptr(), out.data_ptr(), _p(bias), res.data_ptr(), rowscale.data_ptr(), rows_per_scale, N, M, K,
+                w.stride(0), x.stride(0), N, res.stride(0), 1 if FORCE_SMALL_TILE else 0, _stream())
+        _launch(f"gemm_fwd_epi{EPI_RESID}", 2.0 * N * M * K, 2.0 * (N * K + M * K) + 8.0 * N * M,
+                lambda: call("octmae_linear_resid_rowscale", *args))
+        return out
     if mode == "bf16":
         out = torch.empty((M, N), dtype=BF16, device=dev)
         _gemm(w, x, out, N, M, K, w.stride(0), x.stride(0), N, 0, 0, EPI_BF16, bias=bias)
@@ -471,7 +489,8 @@ class BlockFn(torch.autograd.Function):
               produce the proj / fc2 bias gradients (column sums of what they write); GELU' is the fc2-dgrad epilogue."""
 
     @staticmethod
-    def forward(ctx, x, H, eps1, eps2, lp, grads, *params):
+    def forward(ctx, x, H, eps1, eps2, lp, grads, s1, s2, *params):
+        """s1 / s2: None, or fp32 [B] per-sample stochastic-depth factors (0 or 1/keep_prob) of the attention / MLP branch."""
         shp = x.shape
         C = shp[-1]
         Bn, N = shp[0], shp[1]
@@ -483,11 +502,12 @@ class BlockFn(torch.autograd.Function):
         y1, mean1, rstd1 = layernorm_fwd(x2d, g1, be1, eps1)
         qkv = linear_fwd(y1, wqkv, bqkv, "bf16")
         o, lse = attn_fwd(qkv, Bn, N, H, HD, scale)
-        x2 = linear_fwd(o, wproj, bproj, "resid", res=x2d)
+        x2 = linear_fwd(o, wproj, bproj, "resid", res=x2d, rowscale=s1, rows_per_scale=N)
         y2, mean2, rstd2 = layernorm_fwd(x2, g2, be2, eps2)
         pre, act = linear_fwd(y2, w1, b1, "gelu")
-        x3 = linear_fwd(act, w2, b2, "resid", res=x2)
+        x3 = linear_fwd(act, w2, b2, "resid", res=x2, rowscale=s2, rows_per_scale=N)
         ctx.save_for_backward(x2d, mean1, rstd1, y1, qkv, o, lse, x2, mean2, rstd2, y2, pre, act, wqkv, wproj, w1, w2, g1, g2)
+        ctx.scales = (s1, s2)
         ctx.meta = (Bn, N, H, HD, scale, shp)
         ctx.grads, ctx.params = grads, params
         return x3.view(shp)
@@ -500,9 +520,14 @@ class BlockFn(torch.autograd.Function):
         (gg1, gb1n, gg2, gb2n, gwqkv, gbqkv, gwproj, gbproj, gw1, gb1, gw2, gb2) = ctx.grads()
         if dx3.dtype != F32 or not dx3.is_contiguous():
             dx3 = dx3.contiguous().float()
+        s1, s2 = ctx.scales
         side = _sidecar_take(dx3)
         d3 = dx3.view(-1, C)
-        if side is not None:                     # produced by the LayerNorm backward of the next Block
+        if s2 is not None:                       # stochastic depth: the MLP branch sees s2[b] * dx3 (the hand-off is unscaled)
+            d3b = cast_bf16_rowscale(d3, s2, N)
+            if gb2 is not None:
+                colsum_accum(d3b, gb2)
+        elif side is not None:                   # produced by the LayerNorm backward of the next Block
             d3b, colsum3 = side
             d3b = d3b.view(-1, C)
             if gb2 is not None:
@@ -519,7 +544,13 @@ class BlockFn(torch.autograd.Function):
         linear_wgrad_accum(dpre, y2, gw1)
         dy2 = linear_dgrad(dpre, w1)
         # ---- LN2 backward + residual add + bf16 copy + proj bias gradient
-        dx2, dx2b = layernorm_bwd(dy2, x2, mean2, rstd2, g2, gg2, gb2n, dres=d3, want_bf16=True, dxsum=gbproj)
+        if s1 is None:
+            dx2, dx2b = layernorm_bwd(dy2, x2, mean2, rstd2, g2, gg2, gb2n, dres=d3, want_bf16=True, dxsum=gbproj)
+        else:
+            dx2, _ = layernorm_bwd(dy2, x2, mean2, rstd2, g2, gg2, gb2n, dres=d3, want_bf16=False, dxsum=None)
+            dx2b = cast_bf16_rowscale(dx2, s1, N)
+            if gbproj is not None:
+                colsum_accum(dx2b, gbproj)
         # ---- attention
         linear_wgrad_accum(dx2b, o, gwproj)
         do = linear_dgrad(dx2b, wproj)
@@ -534,7 +565,7 @@ class BlockFn(torch.autograd.Function):
         notify_grad_ready(ctx.params)
         dx = dx.view(shp)
         _sidecar_put(dx, dxb.view(shp), colsum)
-        return (dx, None, None, None, None, None) + (None,) * len(ctx.params)
+        return (dx, None, None, None, None, None, None, None) + (None,) * len(ctx.params)
 
 
 class EncAssembleFn(torch.autograd.Function):

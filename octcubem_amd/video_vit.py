@@ -25,12 +25,15 @@ class DropPath(nn.Module):
         super().__init__()
         self.drop_prob = drop_prob
 
+    def sample(self, batch, device):
+        """fp32 [batch] of 0 or 1 / keep_prob: the per-sample factor forward() multiplies in."""
+        keep = 1 - self.drop_prob
+        return (keep + torch.rand(batch, dtype=torch.float32, device=device)).floor_().div_(keep)
+
     def forward(self, x):
         if self.drop_prob == 0.0 or not self.training:
             return x
-        keep = 1 - self.drop_prob
-        shape = (x.shape[0],) + (1,) * (x.ndim - 1)
-        return x.div(keep) * (keep + torch.rand(shape, dtype=x.dtype, device=x.device)).floor_()
+        return x * self.sample(x.shape[0], x.device).to(x.dtype).view((x.shape[0],) + (1,) * (x.ndim - 1))
 
 
 class PatchEmbed(nn.Module):
@@ -282,9 +285,13 @@ class Block(nn.Module):
         x = x.contiguous()
         fused = isinstance(self.attn, (Attention, TimmAttention)) and isinstance(self.norm1, nn.LayerNorm) and \
             isinstance(self.norm2, nn.LayerNorm)
-        if (isinstance(self.drop_path, nn.Identity) or not self.training) and fused:
+        no_drop = isinstance(self.drop_path, nn.Identity) or not self.training or self.drop_path.drop_prob == 0.0
+        if fused:
             _, lp, grads, params = self._v()
-            return ops.BlockFn.apply(x, self.attn.num_heads, self.norm1.eps, self.norm2.eps, lp, grads, *params)
+            s1 = s2 = None
+            if not no_drop:     # stochastic depth: one keep/drop draw per sample and branch, folded into the residual epilogues
+                s1, s2 = self.drop_path.sample(x.shape[0], x.device), self.drop_path.sample(x.shape[0], x.device)
+            return ops.BlockFn.apply(x, self.attn.num_heads, self.norm1.eps, self.norm2.eps, lp, grads, s1, s2, *params)
         if isinstance(self.drop_path, nn.Identity) or not self.training:
             x = self.attn(layer_norm(self.norm1, x), residual=x)
             x = self.mlp(layer_norm(self.norm2, x), residual=x)

@@ -235,16 +235,20 @@ def attention(x, P, prefix, num_heads):
     return F.linear(y, P[f"{prefix}.proj.weight"], P[f"{prefix}.proj.bias"])
 
 
-def block(x, P, prefix, num_heads, eps):
-    """video_vit.py:181-184 with timm Mlp (fc1 -> GELU(erf) -> fc2)."""
+def block(x, P, prefix, num_heads, eps, drop_scales=None):
+    """video_vit.py:181-184 with timm Mlp (fc1 -> GELU(erf) -> fc2).
+    drop_scales = (s1, s2): per-sample stochastic-depth factors, i.e. what timm's DropPath multiplies each branch by in
+    training (floor(keep + U[0,1)) / keep, one draw per sample and branch); None = drop_path 0 / eval."""
     C = x.shape[-1]
+    s1, s2 = (None, None) if drop_scales is None else drop_scales
     h = F.layer_norm(x, (C,), P[f"{prefix}.norm1.weight"], P[f"{prefix}.norm1.bias"], eps)
-    x = x + attention(h, P, f"{prefix}.attn", num_heads)
+    a = attention(h, P, f"{prefix}.attn", num_heads)
+    x = x + (a if s1 is None else a * s1.view(-1, 1, 1))
     h = F.layer_norm(x, (C,), P[f"{prefix}.norm2.weight"], P[f"{prefix}.norm2.bias"], eps)
     h = F.linear(h, P[f"{prefix}.mlp.fc1.weight"], P[f"{prefix}.mlp.fc1.bias"])
     h = F.gelu(h)
     h = F.linear(h, P[f"{prefix}.mlp.fc2.weight"], P[f"{prefix}.mlp.fc2.bias"])
-    return x + h
+    return x + (h if s2 is None else h * s2.view(-1, 1, 1))
 
 
 def patchify(imgs, cfg: MAEConfig):

@@ -102,6 +102,13 @@ def test_gemm_forward_epilogues(M, N, K, tile_variant):
     assert rel(ynb, x.double() @ w.double().t()) < 2e-6
     yr = ops.linear_fwd(x, w, b, "resid", res=res)
     assert rel(yr, ref + res.double()) < 2e-6
+    for rows_per in (d for d in (1, 3, M) if M % d == 0):       # stochastic-depth epilogue: res + scale[row // rows_per] * y
+        sc = torch.tensor([0.0, 1.25, 2.0], device=DEV)[torch.randint(0, 3, (M // rows_per,), generator=g).to(DEV)]
+        ys = ops.linear_fwd(x, w, b, "resid", res=res, rowscale=sc, rows_per_scale=rows_per)
+        exp = res.double() + sc.double().repeat_interleave(rows_per).unsqueeze(1) * ref
+        assert rel(ys, exp) < 2e-6
+        dropped = (sc == 0).repeat_interleave(rows_per)
+        assert torch.equal(ys[dropped], res[dropped])           # a dropped sample passes the residual through bit-exactly
     pre, act = ops.linear_fwd(x, w, b, "gelu")
     assert torch.equal(pre, y16)
     ref_act = torch.nn.functional.gelu(pre.double())
@@ -180,6 +187,10 @@ def test_colsum_and_cast():
     for n in [1, 7, 8, 1000, 65536 * 3 + 5]:
         a = torch.randn(n, generator=g).to(DEV)
         assert torch.equal(ops.cast_bf16(a), a.to(BF16))
+    for R, D, per in [(6, 64, 3), (5121 * 2, 512, 5121), (40, 8, 1)]:
+        a = torch.randn(R, D, generator=g).to(DEV)
+        sc = torch.tensor([0.0, 1.0 / 0.8, 1.0], device=DEV)[torch.arange(R // per, device=DEV) % 3]
+        assert torch.equal(ops.cast_bf16_rowscale(a, sc, per), (a * sc.repeat_interleave(per).unsqueeze(1)).to(BF16))
 
 
 # ------------------------------------------------------------------------------------------------ attention

@@ -272,3 +272,56 @@ def test_fused_block_backward_with_shared_activation():
             if float(ref.norm()) < 1e-6 * float(xr.grad.norm()):
                 continue
             assert rel(p_.grad, ref) <= 5e-2, (i, n_, rel(p_.grad, ref))
+
+
+@pytest.mark.parametrize("attn_kind", ["qkv_separate", "timm_fused"])
+def test_fused_block_stochastic_depth_vs_oracle(attn_kind):
+    """Training-mode Blocks with drop_path > 0: the per-sample keep factors (0 or 1/keep) are folded into the two residual
+    epilogues and into the bf16 gradient casts.  With the draws pinned, forward and every gradient must match the oracle's
+    block evaluated with the same factors (timm DropPath semantics), including samples whose branch is dropped."""
+    from octcubem_amd import video_vit
+    from functools import partial
+    D, H, B, N = 128, 2, 4, 70
+    g = torch.Generator().manual_seed(5)
+    cls = video_vit.Block if attn_kind == "qkv_separate" else video_vit.TimmBlock
+    blocks = [cls(D, H, 4.0, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), drop_path=0.25) for _ in range(2)]
+    P = {}
+    for i, blk in enumerate(blocks):
+        for n_, p_ in blk.named_parameters():
+            with torch.no_grad():
+                p_.copy_(torch.randn(p_.shape, generator=g) * (0.05 if p_.dim() > 1 else 0.02) + (1.0 if "norm" in n_ and n_.endswith("weight") else 0.0))
+            if ".qkv." in n_:
+                for j, nm in enumerate("qkv"):
+                    P[f"blocks.{i}.{n_.replace('.qkv.', '.' + nm + '.')}"] = p_.detach().chunk(3, 0)[j].clone()
+            else:
+                P[f"blocks.{i}.{n_}"] = p_.detach().clone()
+    model = torch.nn.ModuleList(blocks).to(DEV).train()
+    draws = [torch.tensor(v) / 0.75 for v in ([1., 0., 1., 1.], [1., 1., 0., 1.], [0., 1., 1., 1.], [1., 0., 1., 0.])]
+    it = iter(draws)
+    for blk in model:
+        blk.drop_path.sample = lambda batch, device: next(it).to(device)
+    x = torch.randn(B, N, D, generator=g)
+    w = torch.randn(B, N, D, generator=g)
+    xg = x.to(DEV).requires_grad_(True)
+    out = model[1](model[0](xg))
+    (out * w.to(DEV)).sum().backward()
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xr = x.clone().requires_grad_(True)
+    r = O.block(O.block(xr, Pr, "blocks.0", H, 1e-6, (draws[0], draws[1])), Pr, "blocks.1", H, 1e-6, (draws[2], draws[3]))
+    (r * w).sum().backward()
+    assert rel(out, r) <= 1e-2 and rel(xg.grad, xr.grad) <= 3e-2
+    for i, blk in enumerate(model):
+        for n_, p_ in blk.named_parameters():
+            if ".qkv." in n_:
+                ref = torch.cat([Pr[f"blocks.{i}.{n_.replace('.qkv.', '.' + nm + '.')}"].grad for nm in "qkv"], 0)
+            else:
+                ref = Pr[f"blocks.{i}.{n_}"].grad
+            if float(ref.norm()) < 1e-6 * float(xr.grad.norm()) or n_.endswith("attn.k.bias"):
+                continue
+            assert rel(p_.grad, ref) <= 5e-2, (i, n_, rel(p_.grad, ref))
+    # eval mode ignores drop_path entirely
+    model.eval()
+    with torch.no_grad():
+        e = model[1](model[0](x.to(DEV)))
+        re_ = O.block(O.block(x, P, "blocks.0", H, 1e-6), P, "blocks.1", H, 1e-6)
+    assert rel(e, re_) <= 1e-2
