@@ -32,8 +32,12 @@ class MaskedAutoencoderViT(nn.Module):
                  drop_path_rate=0.0, mlp_ratio=4.0, norm_layer=nn.LayerNorm, norm_pix_loss=False, num_frames=16,
                  t_patch_size=4, patch_embed=video_vit.PatchEmbed, no_qkv_bias=False, sep_pos_embed=False,
                  trunc_init=False, cls_embed=False, pred_t_dim=8, high_res_input_size=512, use_flash_attn=False,
-                 **kwargs):
+                 flash_compat=False, **kwargs):
         super().__init__()
+        # flash_compat=True reproduces what the reference computes when it is built with use_flash_attn=True (how the
+        # released OCTCube.pth was trained): the last encoder / decoder block hands only its MLP branch to the final norm,
+        # the residual stream is dropped.  Default: standard pre-norm residual semantics.
+        self.flash_compat = bool(flash_compat)
         if not (sep_pos_embed and cls_embed):
             raise NotImplementedError("the hot path is built for sep_pos_embed=True, cls_embed=True "
                                       "(the reference driver's defaults, main_pretrain…:248-249,283-288)")
@@ -231,8 +235,8 @@ class MaskedAutoencoderViT(nn.Module):
         tok = pe_mod.embed_tokens(imgs, ids_keep)                                    # bf16 [N*nkeep, D]
         pos = self._pos_table(self.pos_embed_spatial, self.pos_embed_temporal, high_res, t_actual)
         x = ops.EncAssembleFn.apply(tok, pos, self.cls_token, self.pos_embed_class, ids_keep)   # fp32 [N, 1+nkeep, D]
-        for blk in self.blocks:
-            x = blk(x)
+        for i, blk in enumerate(self.blocks):
+            x = blk(x, final_residual=not (self.flash_compat and i == len(self.blocks) - 1))
         x = layer_norm(self.norm, x)                                                  # bf16
         x = x[:, 1:, :]
         self._ids_keep = ids_keep
@@ -251,8 +255,8 @@ class MaskedAutoencoderViT(nn.Module):
         dpos = self._pos_table(self.decoder_pos_embed_spatial, self.decoder_pos_embed_temporal, high_res, t_actual)
         x = ops.DecAssembleFn.apply(emb, self.mask_token, dpos, self.decoder_cls_token, self.decoder_pos_embed_class,
                                     ids_restore, ids_keep)                            # fp32 [N, 1+L, Dd]
-        for blk in self.decoder_blocks:
-            x = blk(x)
+        for i, blk in enumerate(self.decoder_blocks):
+            x = blk(x, final_residual=not (self.flash_compat and i == len(self.decoder_blocks) - 1))
         x = layer_norm(self.decoder_norm, x)
         pred_full = self._linear("decoder_pred", x, out_f32=True)                      # fp32 [N, 1+L, PD]
         self._pred_full = pred_full

@@ -20,8 +20,11 @@ class VisionTransformer(nn.Module):
     def __init__(self, num_frames, t_patch_size, img_size=256, patch_size=16, in_chans=1, num_classes=400, embed_dim=768, depth=12,
                  num_heads=12, mlp_ratio=4.0, no_qkv_bias=False, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
                  drop_path_rate=0.0, norm_layer=nn.LayerNorm, dropout=0.5, sep_pos_embed=False, cls_embed=False,
-                 global_pool=False, use_flash_attn=False, **kwargs):
+                 global_pool=False, use_flash_attn=False, flash_compat=False, **kwargs):
         super().__init__()
+        # flash_compat: the last block returns its MLP branch only, as the reference's flash path does
+        # (OCTCube/models_vit_st_flash_attn.py:230-234 keeps ``x`` and drops ``residual``); needed for the released weights
+        self.flash_compat = bool(flash_compat)
         if not (sep_pos_embed and cls_embed):
             raise NotImplementedError("built for sep_pos_embed=True, cls_embed=True (how every reference script calls it)")
         self.global_pool = global_pool
@@ -72,8 +75,8 @@ class VisionTransformer(nn.Module):
             object.__setattr__(self, "_ids", torch.arange(L, device=x.device, dtype=torch.int64).expand(N, L).contiguous())
         x = ops.EncAssembleFn.apply(tok, pos, self.cls_token, self.pos_embed_class, self._ids)   # fp32 [N, 1+L, C]
         hidden_states_list = []
-        for blk in self.blocks:
-            x = blk(x)
+        for i, blk in enumerate(self.blocks):
+            x = blk(x, final_residual=not (self.flash_compat and i == len(self.blocks) - 1))
             hidden_states_list.append(x)
         if hidden_states:
             return hidden_states_list

@@ -489,8 +489,10 @@ class BlockFn(torch.autograd.Function):
               produce the proj / fc2 bias gradients (column sums of what they write); GELU' is the fc2-dgrad epilogue."""
 
     @staticmethod
-    def forward(ctx, x, H, eps1, eps2, lp, grads, s1, s2, *params):
-        """s1 / s2: None, or fp32 [B] per-sample stochastic-depth factors (0 or 1/keep_prob) of the attention / MLP branch."""
+    def forward(ctx, x, H, eps1, eps2, lp, grads, s1, s2, final_residual, *params):
+        """s1 / s2: None, or fp32 [B] per-sample stochastic-depth factors (0 or 1/keep_prob) of the attention / MLP branch.
+        final_residual=False returns the MLP branch alone (flash_compat: what flash-attn's prenorm Block hands back as
+        ``hidden_states`` and the reference's flash models feed to the final norm, models_mae_joint_res_flash_attn.py:480-489)."""
         shp = x.shape
         C = shp[-1]
         Bn, N = shp[0], shp[1]
@@ -505,7 +507,11 @@ class BlockFn(torch.autograd.Function):
         x2 = linear_fwd(o, wproj, bproj, "resid", res=x2d, rowscale=s1, rows_per_scale=N)
         y2, mean2, rstd2 = layernorm_fwd(x2, g2, be2, eps2)
         pre, act = linear_fwd(y2, w1, b1, "gelu")
-        x3 = linear_fwd(act, w2, b2, "resid", res=x2, rowscale=s2, rows_per_scale=N)
+        if final_residual:
+            x3 = linear_fwd(act, w2, b2, "resid", res=x2, rowscale=s2, rows_per_scale=N)
+        else:
+            x3, s2 = linear_fwd(act, w2, b2, "f32"), None
+        ctx.final_residual = final_residual
         ctx.save_for_backward(x2d, mean1, rstd1, y1, qkv, o, lse, x2, mean2, rstd2, y2, pre, act, wqkv, wproj, w1, w2, g1, g2)
         ctx.scales = (s1, s2)
         ctx.meta = (Bn, N, H, HD, scale, shp)
@@ -544,10 +550,11 @@ class BlockFn(torch.autograd.Function):
         linear_wgrad_accum(dpre, y2, gw1)
         dy2 = linear_dgrad(dpre, w1)
         # ---- LN2 backward + residual add + bf16 copy + proj bias gradient
+        dres2 = d3 if ctx.final_residual else None
         if s1 is None:
-            dx2, dx2b = layernorm_bwd(dy2, x2, mean2, rstd2, g2, gg2, gb2n, dres=d3, want_bf16=True, dxsum=gbproj)
+            dx2, dx2b = layernorm_bwd(dy2, x2, mean2, rstd2, g2, gg2, gb2n, dres=dres2, want_bf16=True, dxsum=gbproj)
         else:
-            dx2, _ = layernorm_bwd(dy2, x2, mean2, rstd2, g2, gg2, gb2n, dres=d3, want_bf16=False, dxsum=None)
+            dx2, _ = layernorm_bwd(dy2, x2, mean2, rstd2, g2, gg2, gb2n, dres=dres2, want_bf16=False, dxsum=None)
             dx2b = cast_bf16_rowscale(dx2, s1, N)
             if gbproj is not None:
                 colsum_accum(dx2b, gbproj)
@@ -565,7 +572,7 @@ class BlockFn(torch.autograd.Function):
         notify_grad_ready(ctx.params)
         dx = dx.view(shp)
         _sidecar_put(dx, dxb.view(shp), colsum)
-        return (dx, None, None, None, None, None, None, None) + (None,) * len(ctx.params)
+        return (dx, None, None, None, None, None, None, None, None) + (None,) * len(ctx.params)
 
 
 class EncAssembleFn(torch.autograd.Function):

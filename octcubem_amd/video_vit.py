@@ -279,7 +279,8 @@ class Block(nn.Module):
             object.__setattr__(self, "_views", (arena, (wqkv, bqkv, wproj, bproj, w1, b1, w2, b2), grads, params))
         return self._views
 
-    def forward(self, x):
+    def forward(self, x, final_residual=True):
+        """``final_residual=False`` (flash_compat, last block only): return the MLP branch without the residual stream."""
         if x.dtype != torch.float32:
             x = x.float()
         x = x.contiguous()
@@ -291,7 +292,10 @@ class Block(nn.Module):
             s1 = s2 = None
             if not no_drop:     # stochastic depth: one keep/drop draw per sample and branch, folded into the residual epilogues
                 s1, s2 = self.drop_path.sample(x.shape[0], x.device), self.drop_path.sample(x.shape[0], x.device)
-            return ops.BlockFn.apply(x, self.attn.num_heads, self.norm1.eps, self.norm2.eps, lp, grads, s1, s2, *params)
+            return ops.BlockFn.apply(x, self.attn.num_heads, self.norm1.eps, self.norm2.eps, lp, grads, s1, s2, final_residual,
+                                     *params)
+        if not final_residual:
+            raise NotImplementedError("flash_compat needs the fused Block (Attention / TimmAttention + nn.LayerNorm)")
         if isinstance(self.drop_path, nn.Identity) or not self.training:
             x = self.attn(layer_norm(self.norm1, x), residual=x)
             x = self.mlp(layer_norm(self.norm2, x), residual=x)

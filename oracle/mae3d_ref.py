@@ -235,8 +235,11 @@ def attention(x, P, prefix, num_heads):
     return F.linear(y, P[f"{prefix}.proj.weight"], P[f"{prefix}.proj.bias"])
 
 
-def block(x, P, prefix, num_heads, eps, drop_scales=None):
+def block(x, P, prefix, num_heads, eps, drop_scales=None, final_residual=True):
     """video_vit.py:181-184 with timm Mlp (fc1 -> GELU(erf) -> fc2).
+    final_residual=False: return the MLP branch only -- the ``hidden_states`` flash-attn 2.5.2's prenorm Block
+    (flash_attn/modules/block.py; un-vendored, CUDA only: PARITY UNPINNED for this mode) returns next to ``residual``,
+    which is all the reference's flash path keeps after its last block (models_mae_joint_res_flash_attn.py:480-489).
     drop_scales = (s1, s2): per-sample stochastic-depth factors, i.e. what timm's DropPath multiplies each branch by in
     training (floor(keep + U[0,1)) / keep, one draw per sample and branch); None = drop_path 0 / eval."""
     C = x.shape[-1]
@@ -248,6 +251,8 @@ def block(x, P, prefix, num_heads, eps, drop_scales=None):
     h = F.linear(h, P[f"{prefix}.mlp.fc1.weight"], P[f"{prefix}.mlp.fc1.bias"])
     h = F.gelu(h)
     h = F.linear(h, P[f"{prefix}.mlp.fc2.weight"], P[f"{prefix}.mlp.fc2.bias"])
+    if not final_residual:
+        return h
     return x + (h if s2 is None else h * s2.view(-1, 1, 1))
 
 
@@ -265,7 +270,7 @@ def patchify(imgs, cfg: MAEConfig):
 # --------------------------------------------------------------------------------------
 # model
 # --------------------------------------------------------------------------------------
-def forward_encoder(P, imgs, mask_ratio, noise, cfg: MAEConfig):
+def forward_encoder(P, imgs, mask_ratio, noise, cfg: MAEConfig, flash_compat=False):
     """:374-497."""
     H = imgs.shape[-2]
     high_res = H == cfg.hr_grid[1] * cfg.patch_size
@@ -281,12 +286,12 @@ def forward_encoder(P, imgs, mask_ratio, noise, cfg: MAEConfig):
     pos = torch.cat([P["pos_embed_class"].expand(N, -1, -1), pos], 1)
     x = x + pos
     for i in range(cfg.depth):
-        x = block(x, P, f"blocks.{i}", cfg.num_heads, cfg.ln_eps)
+        x = block(x, P, f"blocks.{i}", cfg.num_heads, cfg.ln_eps, final_residual=not (flash_compat and i == cfg.depth - 1))
     x = F.layer_norm(x, (C,), P["norm.weight"], P["norm.bias"], cfg.ln_eps)
     return x[:, 1:, :], mask, ids_restore
 
 
-def forward_decoder(P, x, ids_restore, cfg: MAEConfig, high_res=False):
+def forward_decoder(P, x, ids_restore, cfg: MAEConfig, high_res=False, flash_compat=False):
     """:499-606."""
     N = x.shape[0]
     x = F.linear(x, P["decoder_embed.weight"], P["decoder_embed.bias"])
@@ -302,7 +307,8 @@ def forward_decoder(P, x, ids_restore, cfg: MAEConfig, high_res=False):
     pos = torch.cat([P["decoder_pos_embed_class"], pos], 1)
     x = x + pos
     for i in range(cfg.decoder_depth):
-        x = block(x, P, f"decoder_blocks.{i}", cfg.decoder_num_heads, cfg.ln_eps)
+        x = block(x, P, f"decoder_blocks.{i}", cfg.decoder_num_heads, cfg.ln_eps,
+                  final_residual=not (flash_compat and i == cfg.decoder_depth - 1))
     x = F.layer_norm(x, (C,), P["decoder_norm.weight"], P["decoder_norm.bias"], cfg.ln_eps)
     x = F.linear(x, P["decoder_pred.weight"], P["decoder_pred.bias"])
     return x[:, 1:, :]
@@ -329,21 +335,21 @@ def forward_loss(imgs, pred, mask, cfg: MAEConfig):
     return (loss * mask).sum() / mask.sum(), frame_losses
 
 
-def forward(P, imgs, cfg: MAEConfig, mask_ratio=0.75, noise=None, frame_loss=False):
+def forward(P, imgs, cfg: MAEConfig, mask_ratio=0.75, noise=None, frame_loss=False, flash_compat=False):
     """:669-680 -- returns (loss, pred, mask) (+ ids_restore for tests)."""
     high_res = imgs.shape[-2] == cfg.hr_grid[1] * cfg.patch_size
-    latent, mask, ids_restore = forward_encoder(P, imgs, mask_ratio, noise, cfg)
-    pred = forward_decoder(P, latent, ids_restore, cfg, high_res)
+    latent, mask, ids_restore = forward_encoder(P, imgs, mask_ratio, noise, cfg, flash_compat)
+    pred = forward_decoder(P, latent, ids_restore, cfg, high_res, flash_compat)
     loss, fl = forward_loss(imgs, pred, mask, cfg)
     if frame_loss:
         return (loss, fl), pred, mask, ids_restore
     return loss, pred, mask, ids_restore
 
 
-def forward_backward(P, imgs, cfg: MAEConfig, mask_ratio=0.75, noise=None):
+def forward_backward(P, imgs, cfg: MAEConfig, mask_ratio=0.75, noise=None, flash_compat=False):
     """One oracle training-step's worth of math: returns loss, pred, mask, ids_restore, grads."""
     Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
-    loss, pred, mask, ids_restore = forward(Pg, imgs, cfg, mask_ratio, noise)
+    loss, pred, mask, ids_restore = forward(Pg, imgs, cfg, mask_ratio, noise, flash_compat=flash_compat)
     loss.backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Pg.items()}
     return loss.detach(), pred.detach(), mask, ids_restore, grads

@@ -83,7 +83,7 @@ def init_from_shapes(shapes, seed, bias_std=0.02):
     return out
 
 
-def vit_st_forward(P, x, cfg: ViTSTConfig):
+def vit_st_forward(P, x, cfg: ViTSTConfig, flash_compat=False):
     """Eval-mode forward (dropout off): logits (N, num_classes) and the pooled embedding."""
     k = (cfg.t_patch_size, cfg.patch_size, cfg.patch_size)
     y = F.conv3d(x, P["patch_embed.proj.weight"], P["patch_embed.proj.bias"], stride=k).flatten(3)
@@ -96,7 +96,7 @@ def vit_st_forward(P, x, cfg: ViTSTConfig):
     pos = torch.cat([P["pos_embed_class"].expand(pos.shape[0], -1, -1), pos], 1)
     y = y + pos
     for i in range(cfg.depth):
-        y = st_block(y, P, f"blocks.{i}", cfg.num_heads, cfg.ln_eps)
+        y = st_block(y, P, f"blocks.{i}", cfg.num_heads, cfg.ln_eps, final_residual=not (flash_compat and i == cfg.depth - 1))
     emb = y[:, 1:, :].mean(dim=1) if cfg.global_pool else y[:, 0]
     return F.linear(emb, P["head.weight"], P["head.bias"]), emb
 

@@ -27,14 +27,14 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def build(cfg: O.MAEConfig, P=None):
+def build(cfg: O.MAEConfig, P=None, **extra):
     from functools import partial
-    m = models_mae.MaskedAutoencoderViT(
+    m = models_mae.MaskedAutoencoderViT(**extra, **dict(
         input_size=cfg.input_size, patch_size=cfg.patch_size, in_chans=cfg.in_chans, embed_dim=cfg.embed_dim, depth=cfg.depth,
         num_heads=cfg.num_heads, decoder_embed_dim=cfg.decoder_embed_dim, decoder_depth=cfg.decoder_depth,
         decoder_num_heads=cfg.decoder_num_heads, mlp_ratio=cfg.mlp_ratio, norm_layer=partial(torch.nn.LayerNorm, eps=cfg.ln_eps),
         norm_pix_loss=cfg.norm_pix_loss, num_frames=cfg.num_frames, t_patch_size=cfg.t_patch_size, sep_pos_embed=True,
-        cls_embed=True, pred_t_dim=cfg.pred_t_dim, high_res_input_size=cfg.high_res_input_size)
+        cls_embed=True, pred_t_dim=cfg.pred_t_dim, high_res_input_size=cfg.high_res_input_size))
     if P is not None:
         missing = m.load_state_dict(P, strict=True)
     return m.to(DEV)
@@ -325,3 +325,60 @@ def test_fused_block_stochastic_depth_vs_oracle(attn_kind):
         e = model[1](model[0](x.to(DEV)))
         re_ = O.block(O.block(x, P, "blocks.0", H, 1e-6), P, "blocks.1", H, 1e-6)
     assert rel(e, re_) <= 1e-2
+
+
+def test_flash_compat_drops_the_final_residual_like_the_flash_path():
+    """flash_compat=True: the last encoder / decoder block hands only its MLP branch to the final norm (what the reference
+    computes when built with use_flash_attn=True).  flash-attn itself cannot run here, so this mode is
+    pinned to the oracle's restatement of flash-attn 2.5.2's prenorm Block only (parity unpinned beyond that)."""
+    cfg = O.MAEConfig(input_size=64, in_chans=1, embed_dim=128, depth=2, num_heads=2, decoder_embed_dim=64, decoder_depth=2,
+                      decoder_num_heads=2, num_frames=6, t_patch_size=3, pred_t_dim=6, high_res_input_size=128)
+    P = O.init_params(cfg, seed=11, bias_std=0.02)
+    imgs = torch.rand(2, 1, 6, 64, 64, generator=torch.Generator().manual_seed(4))
+    noise = torch.rand(2, cfg.num_patches, generator=torch.Generator().manual_seed(5))
+    loss_r, pred_r, mask_r, ids_r, grads_r = O.forward_backward(P, imgs, cfg, 0.75, noise, flash_compat=True)
+    loss_std, pred_std, _, _, _ = O.forward_backward(P, imgs, cfg, 0.75, noise)
+    assert rel(pred_r, pred_std) > 5e-2                      # the two semantics really differ
+    m = build(cfg, P, flash_compat=True)
+    loss, pred, mask = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
+    loss.backward()
+    assert torch.equal(mask.cpu(), mask_r)
+    assert abs(float(loss) - float(loss_r)) <= 2e-3 * float(loss_r) and rel(pred, pred_r) <= 1e-2
+    total = float(O.grad_norm(grads_r.values()))
+    for k, p in m.named_parameters():
+        gr = grads_r[k]
+        if float(gr.norm()) < 1e-6 * total:
+            assert p.grad is None or float(p.grad.double().norm()) <= 1e-4 * total, k
+        else:
+            assert rel(p.grad, gr) <= 5e-2, (k, rel(p.grad, gr))
+
+
+def test_load_pretrained_accepts_flash_layout_and_other_grids():
+    """checkpoint.load_pretrained: a flash-layout checkpoint whose positional tables come from another grid (24 -> 32
+    spatial on the high-res table, 4 -> 2 temporal) loads into the native layout and computes the same thing as the oracle
+    fed the converted weights."""
+    from octcubem_amd import checkpoint as CK
+    cfg = O.MAEConfig(input_size=64, in_chans=1, embed_dim=128, depth=2, num_heads=2, decoder_embed_dim=64, decoder_depth=2,
+                      decoder_num_heads=2, num_frames=6, t_patch_size=3, pred_t_dim=6, high_res_input_size=128)
+    P = O.init_params(cfg, seed=12, bias_std=0.02)
+    g = torch.Generator().manual_seed(8)
+    ck = CK.to_flash_layout(dict(P))
+    assert any(".mixer.Wqkv." in k for k in ck) and not any(".attn.q." in k for k in ck)
+    ck["pos_embed_spatial"] = torch.randn(1, 36, 128, generator=g) * 0.02          # 6x6 grid in the checkpoint, model has 8x8
+    ck["pos_embed_temporal"] = torch.randn(1, 4, 128, generator=g) * 0.02          # 4 temporal slots, model has 2
+    m = build(cfg)
+    missing, unexpected = CK.load_pretrained(m, {"model": ck}, strict=False)
+    assert not unexpected and not [k for k in missing if "decoder_pos_embed" not in k]
+    P2 = dict(P)
+    P2["pos_embed_spatial"] = torch.nn.functional.interpolate(ck["pos_embed_spatial"].reshape(1, 6, 6, 128).permute(0, 3, 1, 2), size=(8, 8),
+                                                               mode="bicubic", align_corners=False).permute(0, 2, 3, 1).flatten(1, 2)
+    P2["pos_embed_temporal"] = torch.nn.functional.interpolate(ck["pos_embed_temporal"].permute(0, 2, 1), size=2, mode="linear",
+                                                                align_corners=False).permute(0, 2, 1)
+    sd = m.state_dict()
+    for k in P2:
+        assert torch.allclose(sd[k].cpu(), P2[k], atol=0), k
+    imgs = torch.rand(2, 1, 6, 64, 64, generator=g)
+    noise = torch.rand(2, cfg.num_patches, generator=g)
+    loss_r, pred_r, _, _ = O.forward(P2, imgs, cfg, 0.75, noise)
+    loss, pred, _ = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
+    assert abs(float(loss) - float(loss_r)) <= 2e-3 * float(loss_r) and rel(pred, pred_r) <= 1e-2

@@ -109,3 +109,50 @@ def test_config1_vitb_2d_mae_full_size_vs_oracle():
     assert torch.equal(mask.cpu(), mask_r) and torch.equal(m._ids_restore.cpu(), ids_r)
     assert abs(float(loss) - float(loss_r)) <= 1e-3 * float(loss_r)
     assert rel(pred, pred_r) <= 1e-2
+
+
+def test_vit_st_flash_compat_and_2d_checkpoint_inflation():
+    """(1) flash_compat on the fine-tune ViT: last block returns its MLP branch only (oracle restatement).
+    (2) checkpoint.load_pretrained from a timm-layout 2-D ViT (fused qkv, Conv2d RGB patch embedding, 1 + 14x14 pos_embed): keys
+    split, patch embedding summed over RGB and inflated over t_patch_size (mean-preserving), pos_embed -> class + resized
+    spatial table; the model then matches the oracle fed the converted tensors."""
+    from octcubem_amd import checkpoint as CK
+    cfg = V.ViTSTConfig(num_frames=6, t_patch_size=3, img_size=64, patch_size=16, in_chans=1, num_classes=8, embed_dim=128, depth=2,
+                        num_heads=2, global_pool=True)
+    P = V.init_from_shapes(V.vit_st_param_shapes(cfg), seed=31)
+    kw = dict(num_frames=6, t_patch_size=3, img_size=64, patch_size=16, in_chans=1, num_classes=8, embed_dim=128, depth=2, num_heads=2,
+              mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), sep_pos_embed=True, cls_embed=True, global_pool=True)
+    x = torch.rand(2, 1, 6, 64, 64, generator=torch.Generator().manual_seed(2))
+    m = models_vit_st.VisionTransformer(flash_compat=True, **kw)
+    m.load_state_dict(P, strict=True)
+    m = m.to(DEV).eval()
+    ref, _ = V.vit_st_forward(P, x, cfg, flash_compat=True)
+    std, _ = V.vit_st_forward(P, x, cfg)
+    assert rel(ref, std) > 5e-2
+    assert rel(m(x.to(DEV)), ref) <= 1e-2
+    # ---- 2-D timm-style checkpoint
+    g = torch.Generator().manual_seed(3)
+    ck = {}
+    for k, v in P.items():
+        if ".attn.q." in k:
+            pre, kind = k.split(".attn.q.")
+            ck[f"{pre}.attn.qkv.{kind}"] = torch.cat([P[f"{pre}.attn.{n}.{kind}"] for n in "qkv"], 0)
+        elif ".attn.k." in k or ".attn.v." in k or k.startswith("pos_embed") or k.startswith("head") or k == "patch_embed.proj.weight":
+            continue
+        else:
+            ck[k] = v
+    ck["patch_embed.proj.weight"] = torch.randn(128, 3, 16, 16, generator=g) * 0.02
+    ck["pos_embed"] = torch.randn(1, 1 + 14 * 14, 128, generator=g) * 0.02
+    m2 = models_vit_st.VisionTransformer(**kw)
+    missing, unexpected = CK.load_pretrained(m2, ck)
+    assert not unexpected and sorted(missing) == ["head.bias", "head.weight", "pos_embed_temporal"]
+    P2 = dict(P)
+    P2["patch_embed.proj.weight"] = ck["patch_embed.proj.weight"].sum(1, keepdim=True).unsqueeze(2).repeat(1, 1, 3, 1, 1) / 3
+    P2["pos_embed_class"] = ck["pos_embed"][:, :1]
+    P2["pos_embed_spatial"] = torch.nn.functional.interpolate(ck["pos_embed"][:, 1:].reshape(1, 14, 14, 128).permute(0, 3, 1, 2), size=(4, 4),
+                                                               mode="bicubic", align_corners=False).permute(0, 2, 3, 1).flatten(1, 2)
+    for k in ("pos_embed_temporal", "head.weight", "head.bias"):
+        P2[k] = m2.state_dict()[k].clone()
+    m2 = m2.to(DEV).eval()
+    ref2, _ = V.vit_st_forward(P2, x, cfg)
+    assert rel(m2(x.to(DEV)), ref2) <= 1e-2
