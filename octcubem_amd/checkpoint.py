@@ -102,6 +102,7 @@ def load_pretrained(model, checkpoint, strict=False, filter_keys=(), smaller_int
     embedding, and positional tables of another grid.  Returns ``load_state_dict``'s (missing, unexpected)."""
     sd = checkpoint.get("model", checkpoint) if isinstance(checkpoint, dict) else checkpoint
     sd = to_native_layout(OrderedDict(sd))
+    flash_model = any(".mixer.Wqkv." in k for k in model.state_dict())
     w = sd.get("patch_embed.proj.weight")
     if w is not None and w.dim() == 4 and model.patch_embed.proj.weight.dim() == 5:
         if w.shape[1] != model.patch_embed.proj.weight.shape[1]:        # RGB 2-D weights -> single-channel volumes
@@ -115,6 +116,8 @@ def load_pretrained(model, checkpoint, strict=False, filter_keys=(), smaller_int
         _fit_sep_tables(model, sd, smaller_interpolate_type)
     else:
         interpolate_pos_embed(model, sd)
+    if flash_model:
+        sd = to_flash_layout(sd)
     own = model.state_dict()
     for k in list(sd.keys()):
         if any(f in k for f in filter_keys) or (k in own and own[k].shape != sd[k].shape and not strict):

@@ -64,13 +64,22 @@ class MaskedAutoencoderViT(nn.Module):
         self.pos_embed_temporal = nn.Parameter(torch.zeros(1, input_size[0], embed_dim))
         self.pos_embed_class = nn.Parameter(torch.zeros(1, 1, embed_dim))
 
-        # use_flash_attn selects flash-attn's fused CUDA blocks in the reference; here attention is ALWAYS the fused
-        # gfx950 kernel, with the standard residual semantics.
-        self.use_flash_attn = False
+        # Attention is ALWAYS the fused gfx950 kernel.  use_flash_attn=True builds what the reference builds with it (:122-152,
+        # :191-220): blocks from the create_block factory (state_dict keys blocks.i.mixer.*), the ``x, residual = blk(x,
+        # residual)`` loop, and therefore the flash path's semantics -- only ``x`` reaches the final norm.
+        self.use_flash_attn = bool(use_flash_attn)
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
-        self.blocks = nn.ModuleList([
-            video_vit.Block(embed_dim, num_heads, mlp_ratio, qkv_bias=not no_qkv_bias, qk_scale=None, norm_layer=norm_layer,
-                            drop_path=dpr[i]) for i in range(depth)])
+        if self.use_flash_attn:
+            self.blocks = nn.ModuleList([
+                video_vit.create_block(embed_dim, num_heads, mlp_ratio, not no_qkv_bias, drop_rate, attn_drop_rate,
+                                       drop_path1=dpr[i - 1] if i > 0 else 0.0, drop_path2=dpr[i], norm_layer=norm_layer,
+                                       act_layer=nn.GELU, use_flash_attn=True, fused_bias_fc=False, fused_mlp=False,
+                                       fused_dropout_add_ln=False, layer_idx=i, n_layer=depth, last_layer_subset=False)
+                for i in range(depth)])
+        else:
+            self.blocks = nn.ModuleList([
+                video_vit.Block(embed_dim, num_heads, mlp_ratio, qkv_bias=not no_qkv_bias, qk_scale=None, norm_layer=norm_layer,
+                                drop_path=dpr[i]) for i in range(depth)])
         self.norm = norm_layer(embed_dim)
         self.decoder_embed = nn.Linear(embed_dim, decoder_embed_dim, bias=True)
         self.mask_token = nn.Parameter(torch.zeros(1, 1, decoder_embed_dim))
@@ -78,9 +87,18 @@ class MaskedAutoencoderViT(nn.Module):
             torch.zeros(1, self.high_res_input_size[1] * self.high_res_input_size[2], decoder_embed_dim))
         self.decoder_pos_embed_temporal = nn.Parameter(torch.zeros(1, input_size[0], decoder_embed_dim))
         self.decoder_pos_embed_class = nn.Parameter(torch.zeros(1, 1, decoder_embed_dim))
-        self.decoder_blocks = nn.ModuleList([
-            video_vit.Block(decoder_embed_dim, decoder_num_heads, mlp_ratio, qkv_bias=not no_qkv_bias, qk_scale=None,
-                            norm_layer=norm_layer) for i in range(decoder_depth)])
+        if self.use_flash_attn:
+            ddpr = [x.item() for x in torch.linspace(0, drop_path_rate, decoder_depth)]
+            self.decoder_blocks = nn.ModuleList([
+                video_vit.create_block(decoder_embed_dim, decoder_num_heads, mlp_ratio, not no_qkv_bias, drop_rate, attn_drop_rate,
+                                       drop_path1=ddpr[i - 1] if i > 0 else 0.0, drop_path2=ddpr[i], norm_layer=norm_layer,
+                                       act_layer=nn.GELU, use_flash_attn=True, fused_bias_fc=False, fused_mlp=False,
+                                       fused_dropout_add_ln=False, layer_idx=i, n_layer=decoder_depth, last_layer_subset=False)
+                for i in range(decoder_depth)])
+        else:
+            self.decoder_blocks = nn.ModuleList([
+                video_vit.Block(decoder_embed_dim, decoder_num_heads, mlp_ratio, qkv_bias=not no_qkv_bias, qk_scale=None,
+                                norm_layer=norm_layer) for i in range(decoder_depth)])
         self.decoder_norm = norm_layer(decoder_embed_dim)
         self.decoder_pred = nn.Linear(decoder_embed_dim, self.t_pred_patch_size * patch_size ** 2 * in_chans, bias=True)
         self.norm_pix_loss = norm_pix_loss
@@ -223,6 +241,16 @@ class MaskedAutoencoderViT(nn.Module):
         return pe.reshape(-1, C)
 
     # ------------------------------------------------------------------ forward pieces
+    def _run_blocks(self, blocks, x):
+        if self.use_flash_attn:                       # :480-483 / :584-587
+            residual = None
+            for blk in blocks:
+                x, residual = blk(x, residual)
+            return x
+        for i, blk in enumerate(blocks):
+            x = blk(x, final_residual=not (self.flash_compat and i == len(blocks) - 1))
+        return x
+
     def forward_encoder(self, x, mask_ratio, pre_mask=None, noise=None):
         assert pre_mask is None
         imgs = x
@@ -235,8 +263,7 @@ class MaskedAutoencoderViT(nn.Module):
         tok = pe_mod.embed_tokens(imgs, ids_keep)                                    # bf16 [N*nkeep, D]
         pos = self._pos_table(self.pos_embed_spatial, self.pos_embed_temporal, high_res, t_actual)
         x = ops.EncAssembleFn.apply(tok, pos, self.cls_token, self.pos_embed_class, ids_keep)   # fp32 [N, 1+nkeep, D]
-        for i, blk in enumerate(self.blocks):
-            x = blk(x, final_residual=not (self.flash_compat and i == len(self.blocks) - 1))
+        x = self._run_blocks(self.blocks, x)
         x = layer_norm(self.norm, x)                                                  # bf16
         x = x[:, 1:, :]
         self._ids_keep = ids_keep
@@ -255,8 +282,7 @@ class MaskedAutoencoderViT(nn.Module):
         dpos = self._pos_table(self.decoder_pos_embed_spatial, self.decoder_pos_embed_temporal, high_res, t_actual)
         x = ops.DecAssembleFn.apply(emb, self.mask_token, dpos, self.decoder_cls_token, self.decoder_pos_embed_class,
                                     ids_restore, ids_keep)                            # fp32 [N, 1+L, Dd]
-        for i, blk in enumerate(self.decoder_blocks):
-            x = blk(x, final_residual=not (self.flash_compat and i == len(self.decoder_blocks) - 1))
+        x = self._run_blocks(self.decoder_blocks, x)
         x = layer_norm(self.decoder_norm, x)
         pred_full = self._linear("decoder_pred", x, out_f32=True)                      # fp32 [N, 1+L, PD]
         self._pred_full = pred_full
@@ -313,16 +339,10 @@ class MaskedAutoencoderViT(nn.Module):
     def load_state_dict_to_backbone(self, state_dict, strict=False, filter_keys=()):
         """Accepts both the non-flash (attn.q/k/v/proj) and the flash (mixer.Wqkv/out_proj) key layouts
         (reference remap rules :693-724, applied in reverse)."""
-        sd = {}
-        for k, v in state_dict.items():
-            k = k.replace(".mixer.out_proj.", ".attn.proj.")
-            if ".mixer.Wqkv." in k:
-                kind = k.rsplit(".", 1)[1]
-                pre = k.split(".mixer.Wqkv.")[0]
-                for i, n in enumerate("qkv"):
-                    sd[f"{pre}.attn.{n}.{kind}"] = v.chunk(3, dim=0)[i].clone()
-                continue
-            sd[k] = v
+        from .checkpoint import to_flash_layout, to_native_layout
+        sd = to_native_layout(state_dict)
+        if self.use_flash_attn:
+            sd = to_flash_layout(sd)
         sd = {k: v for k, v in sd.items() if not any(f in k for f in filter_keys)}
         return super().load_state_dict(sd, strict=strict)
 
@@ -339,7 +359,7 @@ def mae_vit_large_patch16(**kwargs):
 
 def flash_attn_mae_vit_large_patch16(**kwargs):
     """Same architecture; in the reference this factory swaps in flash-attn blocks (:792-803)."""
-    kwargs.pop("use_flash_attn", None)
+    kwargs.setdefault("use_flash_attn", True)
     return mae_vit_large_patch16(**kwargs)
 
 

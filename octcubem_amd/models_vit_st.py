@@ -38,10 +38,20 @@ class VisionTransformer(nn.Module):
         self.pos_embed_temporal = nn.Parameter(torch.zeros(1, input_size[0], embed_dim))
         self.pos_embed_class = nn.Parameter(torch.zeros(1, 1, embed_dim))
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
-        self.use_flash_attn = False     # attention is always the fused gfx950 kernel (standard residual semantics)
-        self.blocks = nn.ModuleList([
-            Block(embed_dim, num_heads, mlp_ratio, qkv_bias=not no_qkv_bias, qk_scale=None, norm_layer=norm_layer, drop_path=dpr[i],
-                  attn_func=partial(Attention, input_size=self.patch_embed.input_size)) for i in range(depth)])
+        # attention is always the fused gfx950 kernel; use_flash_attn=True builds the create_block blocks (keys blocks.i.mixer.*)
+        # and runs the ``x, residual = blk(x, residual)`` loop of models_vit_st_flash_attn.py:123-141,230-234
+        self.use_flash_attn = bool(use_flash_attn)
+        if self.use_flash_attn:
+            self.blocks = nn.ModuleList([
+                video_vit.create_block(embed_dim, num_heads, mlp_ratio, not no_qkv_bias, drop_rate, attn_drop_rate,
+                                       drop_path1=dpr[i - 1] if i > 0 else 0.0, drop_path2=dpr[i], norm_layer=norm_layer,
+                                       act_layer=nn.GELU, use_flash_attn=True, fused_bias_fc=False, fused_mlp=False,
+                                       fused_dropout_add_ln=False, layer_idx=i, n_layer=depth, last_layer_subset=False)
+                for i in range(depth)])
+        else:
+            self.blocks = nn.ModuleList([
+                Block(embed_dim, num_heads, mlp_ratio, qkv_bias=not no_qkv_bias, qk_scale=None, norm_layer=norm_layer, drop_path=dpr[i],
+                      attn_func=partial(Attention, input_size=self.patch_embed.input_size)) for i in range(depth)])
         self.norm = norm_layer(embed_dim)
         self.dropout = nn.Dropout(dropout)
         self.head = nn.Linear(embed_dim, num_classes)
@@ -75,8 +85,12 @@ class VisionTransformer(nn.Module):
             object.__setattr__(self, "_ids", torch.arange(L, device=x.device, dtype=torch.int64).expand(N, L).contiguous())
         x = ops.EncAssembleFn.apply(tok, pos, self.cls_token, self.pos_embed_class, self._ids)   # fp32 [N, 1+L, C]
         hidden_states_list = []
+        residual = None
         for i, blk in enumerate(self.blocks):
-            x = blk(x, final_residual=not (self.flash_compat and i == len(self.blocks) - 1))
+            if self.use_flash_attn:
+                x, residual = blk(x, residual)
+            else:
+                x = blk(x, final_residual=not (self.flash_compat and i == len(self.blocks) - 1))
             hidden_states_list.append(x)
         if hidden_states:
             return hidden_states_list
@@ -100,16 +114,10 @@ class VisionTransformer(nn.Module):
 
     def load_state_dict_to_backbone(self, state_dict, strict=False, filter_keys=()):
         """Accepts flash-layout keys (mixer.Wqkv / mixer.out_proj) as well as the native attn.q/k/v/proj layout."""
-        sd = {}
-        for k, v in state_dict.items():
-            k = k.replace(".mixer.out_proj.", ".attn.proj.")
-            if ".mixer.Wqkv." in k:
-                kind = k.rsplit(".", 1)[1]
-                pre = k.split(".mixer.Wqkv.")[0]
-                for i, n in enumerate("qkv"):
-                    sd[f"{pre}.attn.{n}.{kind}"] = v.chunk(3, dim=0)[i].clone()
-                continue
-            sd[k] = v
+        from .checkpoint import to_flash_layout, to_native_layout
+        sd = to_native_layout(state_dict)
+        if self.use_flash_attn:
+            sd = to_flash_layout(sd)
         sd = {k: v for k, v in sd.items() if not any(f in k for f in filter_keys)}
         return super().load_state_dict(sd, strict=strict)
 
@@ -125,5 +133,5 @@ def vit_large_patch16(**kwargs):
 
 
 def flash_attn_vit_large_patch16(**kwargs):
-    kwargs.pop("use_flash_attn", None)
+    kwargs.setdefault("use_flash_attn", True)
     return vit_large_patch16(**kwargs)

@@ -516,10 +516,12 @@ class BlockFn(torch.autograd.Function):
         ctx.scales = (s1, s2)
         ctx.meta = (Bn, N, H, HD, scale, shp)
         ctx.grads, ctx.params = grads, params
+        if not final_residual:      # (MLP branch, stream before it): the pair flash-attn's prenorm Block returns
+            return x3.view(shp), x2.view(shp)
         return x3.view(shp)
 
     @staticmethod
-    def backward(ctx, dx3):
+    def backward(ctx, dx3, dx2_in=None):
         x2d, mean1, rstd1, y1, qkv, o, lse, x2, mean2, rstd2, y2, pre, act, wqkv, wproj, w1, w2, g1, g2 = ctx.saved_tensors
         Bn, N, H, HD, scale, shp = ctx.meta
         C = H * HD
@@ -550,7 +552,10 @@ class BlockFn(torch.autograd.Function):
         linear_wgrad_accum(dpre, y2, gw1)
         dy2 = linear_dgrad(dpre, w1)
         # ---- LN2 backward + residual add + bf16 copy + proj bias gradient
-        dres2 = d3 if ctx.final_residual else None
+        if ctx.final_residual:
+            dres2 = d3
+        else:                       # gradient arriving through the returned stream (None when only the branch was used)
+            dres2 = None if dx2_in is None else dx2_in.contiguous().float().view(-1, C)
         if s1 is None:
             dx2, dx2b = layernorm_bwd(dy2, x2, mean2, rstd2, g2, gg2, gb2n, dres=dres2, want_bf16=True, dxsum=gbproj)
         else:

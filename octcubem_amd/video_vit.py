@@ -279,12 +279,13 @@ class Block(nn.Module):
             object.__setattr__(self, "_views", (arena, (wqkv, bqkv, wproj, bproj, w1, b1, w2, b2), grads, params))
         return self._views
 
-    def forward(self, x, final_residual=True):
-        """``final_residual=False`` (flash_compat, last block only): return the MLP branch without the residual stream."""
+    def forward(self, x, final_residual=True, return_stream=False):
+        """``final_residual=False`` (flash_compat, last block only): return the MLP branch without the residual stream;
+        with ``return_stream`` also the stream it would have been added to, as a pair."""
         if x.dtype != torch.float32:
             x = x.float()
         x = x.contiguous()
-        fused = isinstance(self.attn, (Attention, TimmAttention)) and isinstance(self.norm1, nn.LayerNorm) and \
+        fused = isinstance(self.attn, (Attention, TimmAttention, FlashMixer)) and isinstance(self.norm1, nn.LayerNorm) and \
             isinstance(self.norm2, nn.LayerNorm)
         no_drop = isinstance(self.drop_path, nn.Identity) or not self.training or self.drop_path.drop_prob == 0.0
         if fused:
@@ -292,8 +293,11 @@ class Block(nn.Module):
             s1 = s2 = None
             if not no_drop:     # stochastic depth: one keep/drop draw per sample and branch, folded into the residual epilogues
                 s1, s2 = self.drop_path.sample(x.shape[0], x.device), self.drop_path.sample(x.shape[0], x.device)
-            return ops.BlockFn.apply(x, self.attn.num_heads, self.norm1.eps, self.norm2.eps, lp, grads, s1, s2, final_residual,
-                                     *params)
+            out = ops.BlockFn.apply(x, self.attn.num_heads, self.norm1.eps, self.norm2.eps, lp, grads, s1, s2, final_residual,
+                                    *params)
+            if final_residual:
+                return out
+            return out if return_stream else out[0]
         if not final_residual:
             raise NotImplementedError("flash_compat needs the fused Block (Attention / TimmAttention + nn.LayerNorm)")
         if isinstance(self.drop_path, nn.Identity) or not self.training:
@@ -312,3 +316,93 @@ class TimmBlock(Block):
                  act_layer=nn.GELU, norm_layer=nn.LayerNorm):
         super().__init__(dim, num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop, attn_drop=attn_drop,
                          drop_path=drop_path, act_layer=act_layer, norm_layer=norm_layer, attn_func=TimmAttention)
+
+
+class FlashMixer(nn.Module):
+    """Parameter layout of flash-attn's ``MHA`` (``Wqkv`` [3D, D] + ``out_proj``): what the reference's flash models hold
+    under ``blocks.i.mixer`` (remap rules at models_mae_joint_res_flash_attn.py:693-724)."""
+
+    def __init__(self, embed_dim, num_heads, qkv_proj_bias=True, out_proj_bias=True):
+        super().__init__()
+        head_dim = embed_dim // num_heads
+        if head_dim not in (32, 64):
+            raise NotImplementedError("the gfx950 attention kernels are built for head_dim 32 and 64")
+        self.num_heads = num_heads
+        self.Wqkv = nn.Linear(embed_dim, 3 * embed_dim, bias=qkv_proj_bias)
+        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=out_proj_bias)
+        self._views = None
+
+    def _v(self):
+        arena = get_arena(self)
+        if self._views is None or self._views[0] is not arena:
+            qkv, pr = self.Wqkv, self.out_proj
+            has_b = qkv.bias is not None
+
+            def grads():
+                return (arena.grad_view(qkv.weight), arena.grad_view(qkv.bias) if has_b else None, arena.grad_view(pr.weight),
+                        arena.grad_view(pr.bias) if pr.bias is not None else None)
+            params = [qkv.weight, pr.weight] + ([qkv.bias] if has_b else []) + ([pr.bias] if pr.bias is not None else [])
+            object.__setattr__(self, "_views", (arena, arena.lp_view(qkv.weight), arena.f32_view(qkv.bias) if has_b else None,
+                                                arena.lp_view(pr.weight), arena.f32_view(pr.bias) if pr.bias is not None else None,
+                                                grads, tuple(params)))
+        return self._views
+
+    def forward(self, x, residual=None):
+        _, wqkv, bqkv, wproj, bproj, grads, params = self._v()
+        return ops.AttentionFn.apply(x, residual, wqkv, bqkv, wproj, bproj, grads, self.num_heads, *params)
+
+
+class FlashBlock(Block):
+    """The module ``flash_attn.models.vit.create_block`` returns, as the reference uses it: pre-norm, residual carried
+    separately, ``forward(hidden_states, residual=None) -> (hidden_states, residual)`` with (flash-attn 2.5.2
+    ``modules/block.py``, prenorm branch; restated -- the package is CUDA-only and absent here):
+
+        residual = drop_path1(hidden_states) + residual          (just hidden_states for the first block)
+        residual = residual + drop_path2(mixer(norm1(residual)))
+        hidden_states = mlp(norm2(residual))
+
+    so a chain of these carries the standard pre-norm stream in ``hidden_states + residual`` and whoever consumes only
+    ``hidden_states`` after the last block (the reference does, models_mae_joint_res_flash_attn.py:480-489) drops the stream.
+    Parameters: ``mixer.Wqkv``, ``mixer.out_proj``, ``norm1``, ``norm2``, ``mlp.fc1``, ``mlp.fc2``."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=True, drop_path1=0.0, drop_path2=0.0, act_layer=nn.GELU,
+                 norm_layer=nn.LayerNorm):
+        nn.Module.__init__(self)
+        self.norm1 = norm_layer(dim)
+        self.mixer = FlashMixer(dim, num_heads, qkv_proj_bias=qkv_bias)
+        self.drop_path1 = DropPath(drop_path1)
+        self.drop_path2 = DropPath(drop_path2)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=0.0)
+        self._views = None
+
+    @property
+    def attn(self):             # Block._v() reads self.attn; not a registered child, so state_dict keys stay ``mixer.*``
+        return self.mixer
+
+    def forward(self, hidden_states, residual=None):
+        x = hidden_states.float()
+        if self.training and self.drop_path1.drop_prob > 0.0:
+            x = self.drop_path1(x)
+        if residual is not None:
+            x = x + residual
+        x = x.contiguous()
+        _, lp, grads, params = self._v()
+        s1 = None
+        if self.training and self.drop_path2.drop_prob > 0.0:
+            s1 = self.drop_path2.sample(x.shape[0], x.device)
+        return ops.BlockFn.apply(x, self.mixer.num_heads, self.norm1.eps, self.norm2.eps, lp, grads, s1, None, False, *params)
+
+
+def create_block(embed_dim, num_heads, mlp_ratio, qkv_bias, drop_rate, attn_drop_rate, drop_path1, drop_path2, norm_layer,
+                 act_layer, use_flash_attn, fused_bias_fc, fused_mlp, fused_dropout_add_ln, layer_idx=None, n_layer=None,
+                 last_layer_subset=False):
+    """Signature of ``flash_attn.models.vit.create_block`` (call sites: models_mae_joint_res_flash_attn.py:131-149,200-218,
+    OCTCube/models_mae_flash_attn.py:109-127, OCTCube/models_vit_st_flash_attn.py:123-141).  The fusion switches select CUDA
+    kernels in flash-attn and are accepted and ignored: everything here is always fused."""
+    if drop_rate != 0.0 or attn_drop_rate != 0.0:
+        raise NotImplementedError("dropout inside the block is not built (every reference call site passes 0)")
+    if last_layer_subset:
+        raise NotImplementedError("last_layer_subset (cls-only last layer) is not built (every reference call site passes False)")
+    return FlashBlock(embed_dim, num_heads, mlp_ratio, qkv_bias=qkv_bias, drop_path1=drop_path1, drop_path2=drop_path2,
+                      act_layer=act_layer, norm_layer=norm_layer)

@@ -382,3 +382,95 @@ def test_load_pretrained_accepts_flash_layout_and_other_grids():
     loss_r, pred_r, _, _ = O.forward(P2, imgs, cfg, 0.75, noise)
     loss, pred, _ = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
     assert abs(float(loss) - float(loss_r)) <= 2e-3 * float(loss_r) and rel(pred, pred_r) <= 1e-2
+
+
+@pytest.mark.parametrize("train_drop", [False, True])
+def test_flash_block_factory_seam(train_drop):
+    """video_vit.create_block: the flash-attn factory signature and ``x, residual = blk(x, residual)`` loop idiom
+    (models_mae_joint_res_flash_attn.py:131-149, 480-483).  hidden + residual after the loop is the standard pre-norm stream
+    (oracle blocks, same weights re-keyed from mixer.Wqkv / mixer.out_proj); hidden alone is the flash_compat output.
+    With stochastic depth the draws are pinned: drop_path1 of block i acts on the MLP branch of block i-1."""
+    from octcubem_amd import video_vit
+    from octcubem_amd import checkpoint as CK
+    from functools import partial
+    D, H, B, N = 128, 4, 3, 70
+    g = torch.Generator().manual_seed(9)
+    dpr = [0.25, 0.25] if train_drop else [0.0, 0.0]
+    blocks = [video_vit.create_block(D, H, 4.0, True, 0.0, 0.0, drop_path1=dpr[i - 1] if i > 0 else 0.0, drop_path2=dpr[i],
+                                     norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), act_layer=torch.nn.GELU, use_flash_attn=True,
+                                     fused_bias_fc=False, fused_mlp=False, fused_dropout_add_ln=False, layer_idx=i, n_layer=2,
+                                     last_layer_subset=False) for i in range(2)]
+    sd = {}
+    for i, blk in enumerate(blocks):
+        for n_, p_ in blk.named_parameters():
+            with torch.no_grad():
+                p_.copy_(torch.randn(p_.shape, generator=g) * (0.05 if p_.dim() > 1 else 0.02) + (1.0 if "norm" in n_ and n_.endswith("weight") else 0.0))
+            sd[f"blocks.{i}.{n_}"] = p_.detach().clone()
+    P = CK.to_native_layout(sd)
+    model = torch.nn.ModuleList(blocks).to(DEV).train(train_drop)
+    draws = None
+    if train_drop:      # block 0: drop_path2 on its attention branch; block 1: drop_path1 on block 0's MLP branch, drop_path2
+        draws = {"b0_dp2": torch.tensor([1., 1., 0.]) / 0.75, "b1_dp1": torch.tensor([1., 0., 1.]) / 0.75,
+                 "b1_dp2": torch.tensor([0., 1., 1.]) / 0.75}
+        model[0].drop_path2.sample = lambda b, d: draws["b0_dp2"].to(d)
+        model[1].drop_path1.sample = lambda b, d: draws["b1_dp1"].to(d)
+        model[1].drop_path2.sample = lambda b, d: draws["b1_dp2"].to(d)
+    x = torch.randn(B, N, D, generator=g)
+    w1 = torch.randn(B, N, D, generator=g); w2 = torch.randn(B, N, D, generator=g)
+    xg = x.to(DEV).requires_grad_(True)
+    hidden, residual = xg, None
+    for blk in model:
+        hidden, residual = blk(hidden, residual)
+    ((hidden * w1.to(DEV)).sum() + (residual * w2.to(DEV)).sum()).backward()
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xr = x.clone().requires_grad_(True)
+    one = torch.ones(B)
+    s_b0 = (draws["b0_dp2"], draws["b1_dp1"]) if train_drop else None
+    r1 = O.block(xr, Pr, "blocks.0", H, 1e-6, s_b0)
+    # block 1, split by hand: stream before its MLP and the MLP branch
+    Cc = D
+    h = torch.nn.functional.layer_norm(r1, (Cc,), Pr["blocks.1.norm1.weight"], Pr["blocks.1.norm1.bias"], 1e-6)
+    a = O.attention(h, Pr, "blocks.1.attn", H)
+    res_ref = r1 + (a * draws["b1_dp2"].view(-1, 1, 1) if train_drop else a)
+    h2 = torch.nn.functional.layer_norm(res_ref, (Cc,), Pr["blocks.1.norm2.weight"], Pr["blocks.1.norm2.bias"], 1e-6)
+    hid_ref = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(h2, Pr["blocks.1.mlp.fc1.weight"], Pr["blocks.1.mlp.fc1.bias"])),
+                                         Pr["blocks.1.mlp.fc2.weight"], Pr["blocks.1.mlp.fc2.bias"])
+    ((hid_ref * w1).sum() + (res_ref * w2).sum()).backward()
+    assert rel(hidden, hid_ref) <= 1e-2 and rel(residual, res_ref) <= 1e-2
+    if not train_drop:
+        std = O.block(O.block(x, P, "blocks.0", H, 1e-6), P, "blocks.1", H, 1e-6)
+        assert rel(hidden + residual, std) <= 1e-2
+    assert rel(xg.grad, xr.grad) <= 3e-2
+    mine = CK.to_native_layout({f"blocks.{i}.{n_}": p_.grad.detach().cpu() for i, blk in enumerate(model) for n_, p_ in blk.named_parameters()})
+    for k, gr in ((k, v.grad) for k, v in Pr.items()):
+        if float(gr.norm()) < 1e-6 * float(xr.grad.norm()) or k.endswith("attn.k.bias"):
+            continue
+        assert rel(mine[k], gr) <= 5e-2, (k, rel(mine[k], gr))
+
+
+def test_use_flash_attn_model_has_flash_keys_and_flash_semantics():
+    """use_flash_attn=True builds create_block blocks: state_dict keys blocks.i.mixer.{Wqkv,out_proj}, and the output is the
+    flash path's (final residual dropped) -- identical to the oracle's flash_compat restatement on the re-keyed weights."""
+    from octcubem_amd import checkpoint as CK
+    cfg = O.MAEConfig(input_size=64, in_chans=1, embed_dim=128, depth=2, num_heads=2, decoder_embed_dim=64, decoder_depth=2,
+                      decoder_num_heads=2, num_frames=6, t_patch_size=3, pred_t_dim=6, high_res_input_size=128)
+    P = O.init_params(cfg, seed=13, bias_std=0.02)
+    m = build(cfg, None, use_flash_attn=True)
+    keys = set(m.state_dict())
+    assert "blocks.0.mixer.Wqkv.weight" in keys and "decoder_blocks.1.mixer.out_proj.bias" in keys and not any(".attn." in k for k in keys)
+    assert keys == set(CK.to_flash_layout(P))
+    missing, unexpected = m.load_state_dict_to_backbone(dict(P), strict=True)          # native-layout checkpoint into the flash model
+    assert not missing and not unexpected
+    imgs = torch.rand(2, 1, 6, 64, 64, generator=torch.Generator().manual_seed(4))
+    noise = torch.rand(2, cfg.num_patches, generator=torch.Generator().manual_seed(5))
+    loss_r, pred_r, mask_r, _, grads_r = O.forward_backward(P, imgs, cfg, 0.75, noise, flash_compat=True)
+    loss, pred, mask = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
+    loss.backward()
+    assert torch.equal(mask.cpu(), mask_r)
+    assert abs(float(loss) - float(loss_r)) <= 2e-3 * float(loss_r) and rel(pred, pred_r) <= 1e-2
+    mine = CK.to_native_layout({k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None})
+    total = float(O.grad_norm(grads_r.values()))
+    for k, gr in grads_r.items():
+        if float(gr.norm()) < 1e-6 * total or k.endswith("attn.k.bias"):
+            continue
+        assert rel(mine[k], gr) <= 5e-2, (k, rel(mine[k], gr))
