@@ -62,19 +62,21 @@ int octmae_layernorm_bwd_ws_floats(int M, int D);
 /* ---- attention -----------------------------------------------------------------------------------
  * softmax(q k^T * scale) v, non-causal, no dropout: video_vit.py:130-134 (flash path: flash_attn MHA,
  * models_mae_joint_res_flash_attn.py:131-149).  qkv bf16 [B][N][3][H][HD]; o, dout bf16 [B][N][H][HD];
- * lse f32 [B][H][N] (natural log); delta_ws f32 [B][H][N] workspace; dqkv bf16 like qkv.  HD in {32, 64}.
+ * lse f32 [B][H][N] (natural log); rowc_ws f32 [2][B][H][N] workspace; dqkv bf16 like qkv.  HD in {32, 64}.
  * flag_ws: one int of device workspace, or NULL.  Non-NULL enables the optimistic forward: a kernel without running-max
  * tracking runs first and raises *flag_ws if any softmax row sum is not a finite positive number; the online-max kernel is
  * always enqueued behind it and returns immediately unless the flag is set (no host synchronisation). */
 int octmae_attn_fwd(const void* qkv, void* o, float* lse, int* flag_ws, int B, int N, int H, int HD, float scale, void* stream);
-int octmae_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta_ws, void* dqkv, int B,
+int octmae_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* rowc_ws, void* dqkv, int B,
                     int N, int H, int HD, float scale, void* stream);
-/* the three launches octmae_attn_bwd is made of (delta = rowsum(dO * O); dQ; dK and dV), callable one by one */
-int octmae_attn_bwd_delta(const void* o, const void* dout, float* delta, int B, int N, int H, int HD, void* stream);
-int octmae_attn_bwd_dq(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int N, int H,
-                       int HD, float scale, void* stream);
-int octmae_attn_bwd_dkv(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int N, int H,
-                        int HD, float scale, void* stream);
+/* the three launches octmae_attn_bwd is made of, callable one by one.  rowconst fills rowc [2][B][H][N] with the per-query
+ * constants the two gradient kernels start their accumulators from: rowc[0] = -lse * log2(e), rowc[1] = -rowsum(dO * O). */
+int octmae_attn_bwd_rowconst(const void* o, const void* dout, const float* lse, float* rowc, int B, int N, int H, int HD,
+                             void* stream);
+int octmae_attn_bwd_dq(const void* qkv, const void* dout, const float* rowc, void* dqkv, int B, int N, int H, int HD, float scale,
+                       void* stream);
+int octmae_attn_bwd_dkv(const void* qkv, const void* dout, const float* rowc, void* dqkv, int B, int N, int H, int HD, float scale,
+                        void* stream);
 
 /* ---- random masking indices ---------------------------------------------------------------------
  * MaskedAutoencoderViT.random_masking index part, models_mae_joint_res_flash_attn.py:349-369:

@@ -22,9 +22,9 @@ SIGNATURES = {
     "octmae_layernorm_bwd_ws_floats": [_i, _i],
     "octmae_attn_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "octmae_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
-    "octmae_attn_bwd_delta": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "octmae_attn_bwd_dq": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
-    "octmae_attn_bwd_dkv": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "octmae_attn_bwd_rowconst": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "octmae_attn_bwd_dq": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "octmae_attn_bwd_dkv": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "octmae_random_masking_ids": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "octmae_cast_f32_bf16": [_vp, _vp, _ll, _vp],
     "octmae_cast_rowscale_f32_bf16": [_vp, _vp, _vp, _ll, _i, _i, _vp],

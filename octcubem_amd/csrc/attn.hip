@@ -32,6 +32,15 @@ namespace octmae {
 #ifndef ATT_OCC_DQ32
 #define ATT_OCC_DQ32 3
 #endif
+#ifndef FWD_RING
+#define FWD_RING(HD) ((HD) == 32 ? 4 : 3)      // K/V ring depth of the forward kernel (LDS: 2 * depth * tile bytes)
+#endif
+#ifndef DKV_RING
+#define DKV_RING(HD) ((HD) == 32 ? 4 : 3)
+#endif
+#ifndef DQ_RING
+#define DQ_RING(HD) ((HD) == 32 ? 4 : 3)
+#endif
 #ifndef ATT_OCC_DKV32
 #define ATT_OCC_DKV32 3
 #endif
@@ -88,6 +97,62 @@ struct TileStage {
     }
   }
 };
+
+// ---- K/V tile ring filled by LDS-DMA -------------------------------------------------------------------------------
+// Tiles go global -> LDS directly (buffer_load_dwordx4 ... lds: no staging registers, no ds_write, no VALU) into an
+// NB-deep ring, NB-1 tiles ahead of their use.  The instruction is issued from inline asm on purpose: the compiler drains
+// vmcnt to 0 before every LDS read it cannot prove disjoint from a tracked LDS-DMA (all ds_read_tr), which would serialise
+// the ring; untracked, the only vmcnt waits in the loop are the counted ones in dma_wait_barrier().  Rows beyond the
+// descriptor's range (keys >= N, and whole tiles past the last one, which are still fetched so that every step issues the
+// same number of loads) read as zero.
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+
+template <int HD, int NWAVES>
+struct TileDma {
+  using T = Tile<HD>;
+  static constexpr int PIECES = T::BYTES / 1024;            // 1-KiB pieces (64 lanes x 16 B) per tile
+  static constexpr int PER_WAVE = PIECES / NWAVES;           // DMA instructions per wave per tile
+  static_assert(PIECES % NWAVES == 0 && PER_WAVE >= 1, "tile pieces must divide over the waves");
+  i32x4_t rsrc;
+  unsigned voff[PER_WAVE];      // per-lane byte offset of this wave's chunk within tile 0
+  unsigned tile_stride;
+  int wid;
+
+  __device__ __forceinline__ void init(const bf16_t* base, size_t row_stride, int nrows, int wid_, int lane) {
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned nrec = (unsigned)(((size_t)(nrows - 1) * row_stride + HD) * 2);
+    rsrc = i32x4_t{(int)(unsigned)a, (int)(unsigned)(a >> 32), (int)nrec, 0x00020000};
+    wid = __builtin_amdgcn_readfirstlane(wid_);
+    tile_stride = (unsigned)(64 * row_stride * 2);
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int q = (wid * PER_WAVE + i) * 64 + lane;        // LDS chunk q  <-  global chunk (row, c ^ swizzle(row))
+      const int row = q / T::CHUNKS, c = (q % T::CHUNKS) ^ T::sw(row);
+      voff[i] = (unsigned)(((size_t)row * row_stride + c * 8) * 2);
+    }
+  }
+  // tile index `t` -> LDS byte address `lds_tile` (wave-uniform)
+  __device__ __forceinline__ void load(int t, unsigned lds_tile) const {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_tile + (unsigned)((wid * PER_WAVE + i) * 1024)));
+      const unsigned off = voff[i] + (unsigned)t * tile_stride;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // m0 is "reserved"; nothing else in these kernels lives in it
+      asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(off), "s"(rsrc) : "memory", "m0");
+#pragma clang diagnostic pop
+    }
+  }
+};
+
+// s_waitcnt vmcnt(CNT) lgkmcnt(0); s_barrier  -- the CNT youngest LDS-DMA loads of this wave stay in flight across the barrier
+template <int CNT>
+__device__ __forceinline__ void dma_wait_barrier() {
+  static_assert(CNT >= 0 && CNT < 64, "vmcnt is 6 bits");
+  // gfx9 s_waitcnt immediate: vmcnt = {[15:14],[3:0]}, expcnt [6:4] = 7 (no wait), lgkmcnt [11:8] = 0
+  __builtin_amdgcn_s_waitcnt((CNT & 15) | ((CNT >> 4) << 14) | (7 << 4) | (0 << 8));
+  __builtin_amdgcn_s_barrier();
+}
 
 // accumulator registers 8s..8s+7 -> bf16 B-operand fragment of k-step s
 __device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int s) {
@@ -175,20 +240,24 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 3)) void attn_fwd_
   // tile t and runs under tile t's exp / convert (VALU); P_t V_t follows.  K is therefore staged one tile ahead of V:
   //   iteration t reads Kbuf[(t+1)&1] (K_{t+1}) and Vbuf[t&1] (V_t); at its end V_{t+1} -> Vbuf[(t+1)&1], K_{t+2} -> Kbuf[t&1].
   const int ntiles = (N + 63) / 64;
-  TileStage<HD> sk, sv;
+  // K/V rings (LDS-DMA, see TileDma): step t issues K_{t+NB} and V_{t+NB-1} into the slots K_t / V_{t-1} left in step t-1
+  // and, before its barrier, waits for everything but the loads of the NB-2 youngest steps: K_{t+2} and V_{t+1}, which
+  // step t+1 reads, have then landed.
+  constexpr int NB = FWD_RING(HD);
   char* const Kbuf = smem;
-  char* const Vbuf = smem + 2 * T::BYTES;
-  sk.issue(kb_, rs, 0, N, tid);
-  sv.issue(vb_, rs, 0, N, tid);
-  sk.commit(Kbuf, tid);
-  sv.commit(Vbuf, tid);
-  if (ntiles > 1) {
-    sk.issue(kb_, rs, 64, N, tid);
-    sk.commit(Kbuf + T::BYTES, tid);
-    sv.issue(vb_, rs, 64, N, tid);
-    if (ntiles > 2) sk.issue(kb_, rs, 128, N, tid);
-  }
-  __syncthreads();
+  char* const Vbuf = smem + NB * T::BYTES;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  TileDma<HD, 4> dk, dv;
+  dk.init(kb_, rs, N, wid, lane);
+  dv.init(vb_, rs, N, wid, lane);
+  constexpr int DMA_CNT = 2 * TileDma<HD, 4>::PER_WAVE * (NB - 2);
+  auto issue = [&](int tk, int tv) {      // K tile tk, V tile tv (a negative tv: a dummy load that keeps the count uniform)
+    dk.load(tk, lds0 + (unsigned)((tk % NB) * T::BYTES));
+    dv.load(tv < 0 ? ntiles + NB : tv, lds0 + (unsigned)((NB + (tv < 0 ? NB - 1 : tv % NB)) * T::BYTES));
+  };
+#pragma unroll
+  for (int s = -NB; s < 0; ++s) issue(s + NB, s + NB - 1);
+  dma_wait_barrier<DMA_CNT>();             // K_0, K_1, V_0 landed and visible
 
   auto qk = [&](const char* cK, f32x16 (&sa)[2]) {
     // row constant -m_s as the initial accumulator (a persistent 16-register tile of it would save the broadcast but
@@ -206,7 +275,8 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 3)) void attn_fwd_
   // tile t: scur = S_t (already computed), snext <- S_{t+1}
   auto step = [&](int t, f32x16 (&scur)[2], f32x16 (&snext)[2], auto last_tag) {
     constexpr bool last = decltype(last_tag)::value;             // compile-time: the masking code must not leak into the loop
-    const char* cV = Vbuf + (t & 1) * T::BYTES;
+    const char* cV = Vbuf + (t % NB) * T::BYTES;
+    issue(t + NB, t + NB - 1);
     if (last) {                                                  // only the last tile can hold keys >= N
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -242,7 +312,7 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 3)) void attn_fwd_
       }
     }
     const bool alias = (&scur[0] == &snext[0]);
-    if (!last && !alias) qk(Kbuf + ((t + 1) & 1) * T::BYTES, snext);      // MFMA pipe works on S_{t+1} under the exps below
+    if (!last && !alias) qk(Kbuf + ((t + 1) % NB) * T::BYTES, snext);     // MFMA pipe works on S_{t+1} under the exps below
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -264,17 +334,8 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 3)) void attn_fwd_
         for (int d = 0; d < DB; ++d) oacc[d] = mfma32(T::tr_frag(cV, kb * 32, s, d * 32, lane), pf, oacc[d]);
         if (ONES_SUM) lacc = mfma32(ones, pf, lacc);
       }
-    if (!last && alias) qk(Kbuf + ((t + 1) & 1) * T::BYTES, snext);
-    // staging for the tiles ahead
-    if (t + 1 < ntiles) {
-      sv.commit(Vbuf + ((t + 1) & 1) * T::BYTES, tid);
-      if (t + 2 < ntiles) {
-        sk.commit(Kbuf + (t & 1) * T::BYTES, tid);
-        sv.issue(vb_, rs, (t + 2) * 64, N, tid);
-        if (t + 3 < ntiles) sk.issue(kb_, rs, (t + 3) * 64, N, tid);
-      }
-    }
-    __syncthreads();
+    if (!last && alias) qk(Kbuf + ((t + 1) % NB) * T::BYTES, snext);
+    dma_wait_barrier<DMA_CNT>();
   };
 
   f32x16 sA[2], sB[2];
@@ -324,7 +385,11 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 3)) void attn_fwd_
 // =====================================================================================================
 template <int HD>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                         float* __restrict__ delta, int BN, int N, int H) {
+                                                         const float* __restrict__ lse, float* __restrict__ rowc, int BN, int N,
+                                                         int H) {
+  // rowc: [2][B*H*N] -- the two per-query constants the backward kernels start their accumulators from:
+  //   rowc[0] = -lse * log2(e)   (S accumulates in the exp2 domain)       rowc[1] = -delta = -rowsum(dO * O)
+  const size_t plane = (size_t)(BN / N) * H * N;
   constexpr int LPH = HD / 8;  // lanes per head
   const int lane = threadIdx.x & 63;
   const int nwaves = gridDim.x * 4;
@@ -342,7 +407,11 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
       }
 #pragma unroll
       for (int m = 1; m < LPH; m <<= 1) s += __shfl_xor(s, m, 64);
-      if (c < nchunk && (lane % LPH) == 0) delta[((size_t)b * H + c / LPH) * N + q] = s;
+      if (c < nchunk && (lane % LPH) == 0) {
+        const size_t i = ((size_t)b * H + c / LPH) * N + q;
+        rowc[i] = -lse[i] * LOG2E;
+        rowc[plane + i] = -s;
+      }
     }
   }
 }
@@ -354,8 +423,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // =====================================================================================================
 template <int HD>
 __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DQ32 : 2)) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                             const float* __restrict__ lse, const float* __restrict__ delta,
-                                                             bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+                                                             const float* __restrict__ rowc, bf16_t* __restrict__ dqkv, int N,
+                                                             int H, float scale) {
   constexpr int KS = HD / 16, DB = HD / 32;
   using T = Tile<HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -383,10 +452,10 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DQ32 : 2)) void attn_bwd_d
     qf[s] = scale_frag(v, sc2);                 // pre-scaled: S^T accumulates in the exp2 domain (used for S only)
     dof[s] = __builtin_bit_cast(bf16x8, w);
   }
-  float lse2 = 0.f, dlt = 0.f;
+  float nlse2 = 0.f, ndlt = 0.f;      // -lse*log2e and -delta of this lane's query (attn_delta_kernel)
   if (qrow < N) {
-    lse2 = lse[((size_t)b * H + head) * N + qrow] * LOG2E;
-    dlt = delta[((size_t)b * H + head) * N + qrow];
+    nlse2 = rowc[((size_t)b * H + head) * N + qrow];
+    ndlt = rowc[(size_t)gridDim.z * H * N + ((size_t)b * H + head) * N + qrow];
   }
 
   f32x16 dq[DB], lse_t, dlt_t;   // row constants replicated over an accumulator tile: out-of-place C operands, set once
@@ -395,24 +464,29 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DQ32 : 2)) void attn_bwd_d
 #pragma unroll
     for (int g = 0; g < 16; ++g) dq[d][g] = 0.f;
 #pragma unroll
-  for (int g = 0; g < 16; ++g) { lse_t[g] = -lse2; dlt_t[g] = -dlt; }
+  for (int g = 0; g < 16; ++g) { lse_t[g] = nlse2; dlt_t[g] = ndlt; }
 
   const int ntiles = (N + 63) / 64;
-  TileStage<HD> sk, sv;
-  sk.issue(kb_, rs, 0, N, tid);
-  sv.issue(vb_, rs, 0, N, tid);
-  sk.commit(smem, tid);
-  sv.commit((smem + 2 * T::BYTES), tid);
-  if (ntiles > 1) {
-    sk.issue(kb_, rs, 64, N, tid);
-    sv.issue(vb_, rs, 64, N, tid);
-  }
-  __syncthreads();
+  // K/V rings filled by LDS-DMA (TileDma): step t issues tile t+NB-1 into the slot tile t-1 left, and waits before its
+  // barrier for everything but the loads of the NB-2 youngest steps, i.e. for tile t+1.
+  constexpr int NB = DQ_RING(HD);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  TileDma<HD, 4> dmk, dmv;
+  dmk.init(kb_, rs, N, wid, lane);
+  dmv.init(vb_, rs, N, wid, lane);
+  constexpr int DMA_CNT = 2 * TileDma<HD, 4>::PER_WAVE * (NB - 2);
+  auto issue = [&](int tt) {
+    dmk.load(tt, lds0 + (unsigned)((tt % NB) * T::BYTES));
+    dmv.load(tt, lds0 + (unsigned)((NB + tt % NB) * T::BYTES));
+  };
+#pragma unroll
+  for (int s = 1 - NB; s < 0; ++s) issue(s + NB - 1);
+  dma_wait_barrier<DMA_CNT>();
 
   auto tile = [&](int t, auto tail_tag) {
     constexpr bool TAIL = decltype(tail_tag)::value;
-    const char* cK = (smem + (t & 1) * T::BYTES);
-    const char* cV = (smem + (2 + (t & 1)) * T::BYTES);
+    const char* cK = (smem + (t % NB) * T::BYTES);
+    const char* cV = (smem + (NB + t % NB) * T::BYTES);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 sa, dp;
@@ -440,14 +514,9 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DQ32 : 2)) void attn_bwd_d
     }
   };
   for (int t = 0; t + 1 < ntiles; ++t) {
+    issue(t + NB - 1);
     tile(t, std::false_type{});
-    sk.commit((smem + ((t + 1) & 1) * T::BYTES), tid);
-    sv.commit((smem + (2 + ((t + 1) & 1)) * T::BYTES), tid);
-    if (t + 2 < ntiles) {
-      sk.issue(kb_, rs, (t + 2) * 64, N, tid);
-      sv.issue(vb_, rs, (t + 2) * 64, N, tid);
-    }
-    __syncthreads();
+    dma_wait_barrier<DMA_CNT>();
   }
   tile(ntiles - 1, std::true_type{});   // last tile: the only one that can hold keys >= N
 #pragma unroll
@@ -474,13 +543,14 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DQ32 : 2)) void attn_bwd_d
 // =====================================================================================================
 template <int HD>
 __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DKV32 : 2)) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                              const float* __restrict__ lse, const float* __restrict__ delta,
-                                                              bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+                                                              const float* __restrict__ rowc, bf16_t* __restrict__ dqkv, int N,
+                                                              int H, float scale) {
   constexpr int KS = HD / 16, DB = HD / 32;
+  constexpr int NB = DKV_RING(HD);
   using T = Tile<HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // LDS: Q0 Q1 O0 O1
-  float* ldsC = reinterpret_cast<float*>(smem + 4 * T::BYTES);  // [2 buffers][2: -lse*log2e, -delta][64]
+  // LDS rings (LDS-DMA, see TileDma): Q [NB] | dO [NB] | row constants [NB][2: -lse*log2e, -delta][64] f32
+  const float* ldsC = reinterpret_cast<const float*>(smem + 2 * NB * T::BYTES);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -491,8 +561,6 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DKV32 : 2)) void attn_bwd_
   const bf16_t* kb_ = qb + (size_t)H * HD;
   const bf16_t* vb_ = qb + (size_t)2 * H * HD;
   const bf16_t* dob = dout + (size_t)b * N * ostride + (size_t)head * HD;
-  const float* lse_b = lse + ((size_t)b * H + head) * N;
-  const float* dlt_b = delta + ((size_t)b * H + head) * N;
   const int krow = blockIdx.x * 128 + wid * 32 + r;
   const float sc2 = scale * LOG2E;
 
@@ -515,38 +583,35 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DKV32 : 2)) void attn_bwd_
     for (int g = 0; g < 16; ++g) { dk[d][g] = 0.f; dv[d][g] = 0.f; }
 
   const int ntiles = (N + 63) / 64;
-  TileStage<HD> sq, so;
-  float c_lse = 0.f, c_dlt = 0.f;  // threads 0..63 stage the row constants of one tile
-  auto issue_consts = [&](int row0) {
-    if (tid < 64) {
-      const int q = row0 + tid;
-      c_lse = (q < N) ? -lse_b[q] * LOG2E : 0.f;
-      c_dlt = (q < N) ? -dlt_b[q] : 0.f;
-    }
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  TileDma<HD, 4> dmq, dmo;
+  dmq.init(qb, rs, N, wid, lane);
+  dmo.init(dob, ostride, N, wid, lane);
+  // row constants: one 256-byte dword DMA per wave and tile -- waves 0/2 fetch the -lse*log2e row, waves 1/3 the -delta row
+  // (2 and 3 repeat 0 and 1 so that every wave has the same number of loads in flight); queries >= N read as zero
+  const int uw = __builtin_amdgcn_readfirstlane(wid);
+  const unsigned long long ca = (unsigned long long)(rowc + (size_t)(uw & 1) * gridDim.z * H * N + ((size_t)b * H + head) * N);
+  const i32x4_t rc = {(int)(unsigned)ca, (int)(unsigned)(ca >> 32), (int)(unsigned)((size_t)N * 4), 0x00020000};
+  constexpr int DMA_CNT = (2 * TileDma<HD, 4>::PER_WAVE + 1) * (NB - 2);
+  auto issue = [&](int tt) {
+    dmq.load(tt, lds0 + (unsigned)((tt % NB) * T::BYTES));
+    dmo.load(tt, lds0 + (unsigned)((NB + tt % NB) * T::BYTES));
+    const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(2 * NB * T::BYTES + (tt % NB) * 512 + (uw & 1) * 256)));
+    const unsigned off = (unsigned)((tt * 64 + lane) * 4);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(m0v), "v"(off), "s"(rc) : "memory", "m0");
+#pragma clang diagnostic pop
   };
-  auto commit_consts = [&](int buf) {
-    if (tid < 64) {
-      ldsC[buf * 128 + tid] = c_lse;
-      ldsC[buf * 128 + 64 + tid] = c_dlt;
-    }
-  };
-  sq.issue(qb, rs, 0, N, tid);
-  so.issue(dob, ostride, 0, N, tid);
-  issue_consts(0);
-  sq.commit(smem, tid);
-  so.commit((smem + 2 * T::BYTES), tid);
-  commit_consts(0);
-  if (ntiles > 1) {
-    sq.issue(qb, rs, 64, N, tid);
-    so.issue(dob, ostride, 64, N, tid);
-    issue_consts(64);
-  }
-  __syncthreads();
+#pragma unroll
+  for (int s = 1 - NB; s < 0; ++s) issue(s + NB - 1);
+  dma_wait_barrier<DMA_CNT>();
 
   for (int t = 0; t < ntiles; ++t) {
-    const char* cQ = (smem + (t & 1) * T::BYTES);
-    const char* cO = (smem + (2 + (t & 1)) * T::BYTES);
-    const float* cC = ldsC + (t & 1) * 128;
+    issue(t + NB - 1);
+    const char* cQ = (smem + (t % NB) * T::BYTES);
+    const char* cO = (smem + (NB + t % NB) * T::BYTES);
+    const float* cC = ldsC + (t % NB) * 128;
 #pragma unroll
     for (int qb32 = 0; qb32 < 2; ++qb32) {
       f32x16 sa, dp;
@@ -579,17 +644,7 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DKV32 : 2)) void attn_bwd_
         }
       }
     }
-    if (t + 1 < ntiles) {
-      sq.commit((smem + ((t + 1) & 1) * T::BYTES), tid);
-      so.commit((smem + (2 + ((t + 1) & 1)) * T::BYTES), tid);
-      commit_consts((t + 1) & 1);
-      if (t + 2 < ntiles) {
-        sq.issue(qb, rs, (t + 2) * 64, N, tid);
-        so.issue(dob, ostride, (t + 2) * 64, N, tid);
-        issue_consts((t + 2) * 64);
-      }
-    }
-    __syncthreads();
+    dma_wait_barrier<DMA_CNT>();
   }
 #pragma unroll
   for (int d = 0; d < DB; ++d)
@@ -611,7 +666,7 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DKV32 : 2)) void attn_bwd_
 
 template <int HD>
 static int run_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, int H, float scale, int* flag, hipStream_t st) {
-  const int lds = 4 * Tile<HD>::BYTES;
+  const int lds = 2 * FWD_RING(HD) * Tile<HD>::BYTES;
   dim3 grid((N + 127) / 128, H, B);
   if (flag != nullptr) {      // optimistic kernel, then the safe one (a no-op unless the flag was raised)
     hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st);
@@ -625,27 +680,27 @@ static int run_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int B, int N, int H
 }
 
 template <int HD>
-static int run_delta(const bf16_t* o, const bf16_t* dout, float* delta, int B, int N, int H, hipStream_t st) {
+static int run_delta(const bf16_t* o, const bf16_t* dout, const float* lse, float* rowc, int B, int N, int H, hipStream_t st) {
   int blocks = (B * N + 3) / 4;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3(blocks), dim3(256), 0, st, o, dout, delta, B * N, N, H);
+  hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3(blocks), dim3(256), 0, st, o, dout, lse, rowc, B * N, N, H);
   OCTMAE_LAUNCH_CHECK();
   return 0;
 }
 template <int HD>
-static int run_dq(const bf16_t* qkv, const bf16_t* dout, const float* lse, const float* delta, bf16_t* dqkv, int B, int N, int H,
-                  float scale, hipStream_t st) {
+static int run_dq(const bf16_t* qkv, const bf16_t* dout, const float* rowc, bf16_t* dqkv, int B, int N, int H, float scale,
+                  hipStream_t st) {
   dim3 grid((N + 127) / 128, H, B);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, grid, dim3(256), 4 * Tile<HD>::BYTES, st, qkv, dout, lse, delta, dqkv, N, H, scale);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, grid, dim3(256), 2 * DQ_RING(HD) * Tile<HD>::BYTES, st, qkv, dout, rowc, dqkv, N, H, scale);
   OCTMAE_LAUNCH_CHECK();
   return 0;
 }
 template <int HD>
-static int run_dkv(const bf16_t* qkv, const bf16_t* dout, const float* lse, const float* delta, bf16_t* dqkv, int B, int N, int H,
-                   float scale, hipStream_t st) {
+static int run_dkv(const bf16_t* qkv, const bf16_t* dout, const float* rowc, bf16_t* dqkv, int B, int N, int H, float scale,
+                   hipStream_t st) {
   dim3 grid((N + 127) / 128, H, B);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel<HD>, grid, dim3(256), 4 * Tile<HD>::BYTES + 1024, st, qkv, dout, lse, delta, dqkv, N, H,
-                     scale);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<HD>, grid, dim3(256), DKV_RING(HD) * (2 * Tile<HD>::BYTES + 512), st, qkv, dout, rowc, dqkv,
+                     N, H, scale);
   OCTMAE_LAUNCH_CHECK();
   return 0;
 }
@@ -663,33 +718,33 @@ extern "C" int octmae_attn_fwd(const void* qkv, void* o, float* lse, int* flag_w
 }
 
 #define BFP(x) reinterpret_cast<const bf16_t*>(x)
-extern "C" int octmae_attn_bwd_delta(const void* o, const void* dout, float* delta, int B, int N, int H, int HD, void* stream) {
-  OCTMAE_CHECK_ARG(o && dout && delta && B > 0 && N > 0 && H > 0 && (HD == 64 || HD == 32));
+extern "C" int octmae_attn_bwd_rowconst(const void* o, const void* dout, const float* lse, float* rowc, int B, int N, int H, int HD,
+                                        void* stream) {
+  OCTMAE_CHECK_ARG(o && dout && lse && rowc && B > 0 && N > 0 && H > 0 && (HD == 64 || HD == 32));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  return HD == 64 ? run_delta<64>(BFP(o), BFP(dout), delta, B, N, H, st) : run_delta<32>(BFP(o), BFP(dout), delta, B, N, H, st);
+  return HD == 64 ? run_delta<64>(BFP(o), BFP(dout), lse, rowc, B, N, H, st) : run_delta<32>(BFP(o), BFP(dout), lse, rowc, B, N, H, st);
 }
-extern "C" int octmae_attn_bwd_dq(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int N,
-                                  int H, int HD, float scale, void* stream) {
-  OCTMAE_CHECK_ARG(qkv && dout && lse && delta && dqkv && B > 0 && N > 0 && H > 0 && (HD == 64 || HD == 32));
+extern "C" int octmae_attn_bwd_dq(const void* qkv, const void* dout, const float* rowc, void* dqkv, int B, int N, int H, int HD,
+                                  float scale, void* stream) {
+  OCTMAE_CHECK_ARG(qkv && dout && rowc && dqkv && B > 0 && N > 0 && H > 0 && (HD == 64 || HD == 32));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   bf16_t* d = reinterpret_cast<bf16_t*>(dqkv);
-  return HD == 64 ? run_dq<64>(BFP(qkv), BFP(dout), lse, delta, d, B, N, H, scale, st)
-                  : run_dq<32>(BFP(qkv), BFP(dout), lse, delta, d, B, N, H, scale, st);
+  return HD == 64 ? run_dq<64>(BFP(qkv), BFP(dout), rowc, d, B, N, H, scale, st) : run_dq<32>(BFP(qkv), BFP(dout), rowc, d, B, N, H, scale, st);
 }
-extern "C" int octmae_attn_bwd_dkv(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int N,
-                                   int H, int HD, float scale, void* stream) {
-  OCTMAE_CHECK_ARG(qkv && dout && lse && delta && dqkv && B > 0 && N > 0 && H > 0 && (HD == 64 || HD == 32));
+extern "C" int octmae_attn_bwd_dkv(const void* qkv, const void* dout, const float* rowc, void* dqkv, int B, int N, int H, int HD,
+                                   float scale, void* stream) {
+  OCTMAE_CHECK_ARG(qkv && dout && rowc && dqkv && B > 0 && N > 0 && H > 0 && (HD == 64 || HD == 32));
+  OCTMAE_CHECK_ARG((size_t)N * 4 < 0xFFFFFFFFull);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   bf16_t* d = reinterpret_cast<bf16_t*>(dqkv);
-  return HD == 64 ? run_dkv<64>(BFP(qkv), BFP(dout), lse, delta, d, B, N, H, scale, st)
-                  : run_dkv<32>(BFP(qkv), BFP(dout), lse, delta, d, B, N, H, scale, st);
+  return HD == 64 ? run_dkv<64>(BFP(qkv), BFP(dout), rowc, d, B, N, H, scale, st) : run_dkv<32>(BFP(qkv), BFP(dout), rowc, d, B, N, H, scale, st);
 }
 // convenience: the three launches above, in order
-extern "C" int octmae_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta_ws, void* dqkv,
+extern "C" int octmae_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* rowc_ws, void* dqkv,
                                int B, int N, int H, int HD, float scale, void* stream) {
-  int rc = octmae_attn_bwd_delta(o, dout, delta_ws, B, N, H, HD, stream);
+  int rc = octmae_attn_bwd_rowconst(o, dout, lse, rowc_ws, B, N, H, HD, stream);
   if (rc) return rc;
-  rc = octmae_attn_bwd_dq(qkv, dout, lse, delta_ws, dqkv, B, N, H, HD, scale, stream);
+  rc = octmae_attn_bwd_dq(qkv, dout, rowc_ws, dqkv, B, N, H, HD, scale, stream);
   if (rc) return rc;
-  return octmae_attn_bwd_dkv(qkv, dout, lse, delta_ws, dqkv, B, N, H, HD, scale, stream);
+  return octmae_attn_bwd_dkv(qkv, dout, rowc_ws, dqkv, B, N, H, HD, scale, stream);
 }

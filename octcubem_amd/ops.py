@@ -251,17 +251,17 @@ def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, HD: int, scale: float, o
 
 def attn_bwd(qkv, o, dout, lse, B, N, H, HD, scale):
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty((B, H, N), dtype=F32, device=qkv.device)
+    rowc = torch.empty((2, B, H, N), dtype=F32, device=qkv.device)      # -lse*log2e | -rowsum(dO * O)
     st = _stream()
-    call("octmae_attn_bwd_delta", o.data_ptr(), dout.data_ptr(), delta.data_ptr(), B, N, H, HD, st)
+    call("octmae_attn_bwd_rowconst", o.data_ptr(), dout.data_ptr(), lse.data_ptr(), rowc.data_ptr(), B, N, H, HD, st)
     # algorithmic backward = 5 matmuls (10 B H N^2 HD flop); dq executes 3 of them, dkv 4 (S and dP are recomputed twice)
     unit = 2.0 * B * H * N * N * HD
     _launch(f"attn_bwd_dq_hd{HD}", 2 * unit, 2.0 * 5 * B * N * H * HD,
-            lambda: call("octmae_attn_bwd_dq", qkv.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, N,
-                         H, HD, float(scale), st))
+            lambda: call("octmae_attn_bwd_dq", qkv.data_ptr(), dout.data_ptr(), rowc.data_ptr(), dqkv.data_ptr(), B, N, H, HD,
+                         float(scale), st))
     _launch(f"attn_bwd_dkv_hd{HD}", 3 * unit, 2.0 * 6 * B * N * H * HD,
-            lambda: call("octmae_attn_bwd_dkv", qkv.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, N,
-                         H, HD, float(scale), st))
+            lambda: call("octmae_attn_bwd_dkv", qkv.data_ptr(), dout.data_ptr(), rowc.data_ptr(), dqkv.data_ptr(), B, N, H, HD,
+                         float(scale), st))
     return dqkv
 
 

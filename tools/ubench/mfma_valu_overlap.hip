@@ -13,11 +13,13 @@ __global__ __launch_bounds__(512, 1) void k(float* out, int iters, int mode, int
   f32x16 c0 = {0}, c1 = {0};
   float x0 = threadIdx.x * 1e-3f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + .5f, x5 = x0 + .25f;
   if (wid >= 4 && (mode == 2 || mode == 5 || mode == 7 || mode == 9)) iters *= vmul;
-  const bool do_mfma = (mode == 0) || ((mode == 2 || mode == 5 || mode == 7 || mode == 9) && wid < 4);
+  if (wid < 4 && (mode == 10 || mode == 11)) iters *= vmul;
+  const bool do_mfma = (mode == 0) || ((mode == 2 || mode == 5 || mode == 7 || mode == 9) && wid < 4) || ((mode == 10 || mode == 11) && wid >= 4);
+  if (mode == 11 && wid >= 4) __builtin_amdgcn_s_setprio(3);
   const bool do_exp = (mode == 1) || (mode == 2 && wid >= 4);
   const bool do_fma = (mode == 4) || (mode == 5 && wid >= 4);
   const bool do_cvt = (mode == 6) || (mode == 7 && wid >= 4);
-  const bool do_mix = (mode == 8) || (mode == 9 && wid >= 4);
+  const bool do_mix = (mode == 8) || (mode == 9 && wid >= 4) || ((mode == 10 || mode == 11) && wid < 4);
   if (mode == 3) {
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
@@ -74,12 +76,14 @@ __global__ __launch_bounds__(512, 1) void k(float* out, int iters, int mode, int
 int main() {
   float* d; hipMalloc(&d, 64); hipMemset(d, 0, 64);
   const int iters = 2000;
-  const char* names[10] = {"all waves MFMA (32 per iter per wave)", "all waves v_exp (96 per iter per wave)",
+  const char* names[12] = {"all waves MFMA (32 per iter per wave)", "all waves v_exp (96 per iter per wave)",
                           "waves 0-3 MFMA, 4-7 v_exp (one of each per SIMD)", "every wave: 16 MFMA + 48 v_exp interleaved",
-    "all waves v_fma (96/iter)", "waves 0-3 MFMA, 4-7 v_fma", "all waves v_cvt_pk (96/iter)", "waves 0-3 MFMA, 4-7 v_cvt_pk", "all waves softmax-mix (96/iter)", "waves 0-3 MFMA, 4-7 softmax-mix"};
+    "all waves v_fma (96/iter)", "waves 0-3 MFMA, 4-7 v_fma", "all waves v_cvt_pk (96/iter)", "waves 0-3 MFMA, 4-7 v_cvt_pk", "all waves softmax-mix (96/iter)", "waves 0-3 MFMA, 4-7 softmax-mix",
+    "waves 0-3 softmax-mix (OLDER), 4-7 MFMA", "same, MFMA waves at s_setprio 3"};
   for (int vmul = 1; vmul <= 4; vmul *= 2)
-  for (int mode = 0; mode < 10; ++mode) {
-    if (vmul > 1 && !(mode == 2 || mode == 5 || mode == 7 || mode == 9)) continue;
+  for (int mode = 0; mode < 12; ++mode) {
+    if (vmul > 1 && !(mode == 9 || mode == 10 || mode == 11)) continue;
+    if (vmul == 1 && mode < 8) continue;
     hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, d, iters, mode, vmul);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

@@ -36,6 +36,34 @@ __global__ void k(float* out, int iters, float a0) {
         asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %2\n v_add_f32 %0, %0, %3\n v_add_f32 %0, %0, %4\n"
                      "v_add_f32 %0, %0, %5\n v_add_f32 %0, %0, %6\n v_add_f32 %0, %0, %7\n v_add_f32 %0, %0, %1\n"
                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+      } else if (OP == 7) {  // v_pk_fma_f16 x8
+        asm volatile("v_pk_fma_f16 %0, %0, %0, %0\n v_pk_fma_f16 %1, %1, %1, %1\n v_pk_fma_f16 %2, %2, %2, %2\n v_pk_fma_f16 %3, %3, %3, %3\n"
+                     "v_pk_fma_f16 %4, %4, %4, %4\n v_pk_fma_f16 %5, %5, %5, %5\n v_pk_fma_f16 %6, %6, %6, %6\n v_pk_fma_f16 %7, %7, %7, %7\n"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+      } else if (OP == 8) {  // v_pk_add_u16 x8
+        asm volatile("v_pk_add_u16 %0, %0, %1\n v_pk_add_u16 %1, %1, %2\n v_pk_add_u16 %2, %2, %3\n v_pk_add_u16 %3, %3, %4\n"
+                     "v_pk_add_u16 %4, %4, %5\n v_pk_add_u16 %5, %5, %6\n v_pk_add_u16 %6, %6, %7\n v_pk_add_u16 %7, %7, %0\n"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+      } else if (OP == 9) {  // v_pk_lshlrev_b16 x8
+        asm volatile("v_pk_lshlrev_b16 %0, 3, %0\n v_pk_lshlrev_b16 %1, 3, %1\n v_pk_lshlrev_b16 %2, 3, %2\n v_pk_lshlrev_b16 %3, 3, %3\n"
+                     "v_pk_lshlrev_b16 %4, 3, %4\n v_pk_lshlrev_b16 %5, 3, %5\n v_pk_lshlrev_b16 %6, 3, %6\n v_pk_lshlrev_b16 %7, 3, %7\n"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+      } else if (OP == 10) {  // v_cvt_pkrtz_f16_f32 x8
+        asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1\n v_cvt_pkrtz_f16_f32 %1, %1, %2\n v_cvt_pkrtz_f16_f32 %2, %2, %3\n v_cvt_pkrtz_f16_f32 %3, %3, %4\n"
+                     "v_cvt_pkrtz_f16_f32 %4, %4, %5\n v_cvt_pkrtz_f16_f32 %5, %5, %6\n v_cvt_pkrtz_f16_f32 %6, %6, %7\n v_cvt_pkrtz_f16_f32 %7, %7, %0\n"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+      } else if (OP == 11) {  // v_exp_f16 x8
+        asm volatile("v_exp_f16 %0, %0\n v_exp_f16 %1, %1\n v_exp_f16 %2, %2\n v_exp_f16 %3, %3\n"
+                     "v_exp_f16 %4, %4\n v_exp_f16 %5, %5\n v_exp_f16 %6, %6\n v_exp_f16 %7, %7\n"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+      } else if (OP == 12) {  // v_ldexp_f32 x8
+        asm volatile("v_ldexp_f32 %0, %0, %1\n v_ldexp_f32 %1, %1, %2\n v_ldexp_f32 %2, %2, %3\n v_ldexp_f32 %3, %3, %4\n"
+                     "v_ldexp_f32 %4, %4, %5\n v_ldexp_f32 %5, %5, %6\n v_ldexp_f32 %6, %6, %7\n v_ldexp_f32 %7, %7, %0\n"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+      } else if (OP == 13) {  // v_perm_b32 x8
+        asm volatile("v_perm_b32 %0, %0, %1, %2\n v_perm_b32 %1, %1, %2, %3\n v_perm_b32 %2, %2, %3, %4\n v_perm_b32 %3, %3, %4, %5\n"
+                     "v_perm_b32 %4, %4, %5, %6\n v_perm_b32 %5, %5, %6, %7\n v_perm_b32 %6, %6, %7, %0\n v_perm_b32 %7, %7, %0, %1\n"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
       } else if (OP == 6) {  // v_pk_mul_f32 x8
         asm volatile("v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %2\n v_pk_mul_f32 %2, %2, %3\n v_pk_mul_f32 %3, %3, %0\n"
                      "v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %2\n v_pk_mul_f32 %2, %2, %3\n v_pk_mul_f32 %3, %3, %0\n"
@@ -52,7 +80,7 @@ template <int OP>
 void run(const char* name) {
   float* d; hipMalloc(&d, 64);
   const int iters = 2000;
-  for (int waves : {1, 2, 4, 8}) {   // waves per SIMD: block of 256*waves/... use blocks of 256 threads (1 wave per SIMD each), `waves` blocks per CU
+  for (int waves : {1, 2, 4}) {   // waves per SIMD: block of 256*waves/... use blocks of 256 threads (1 wave per SIMD each), `waves` blocks per CU
     float h[2];
     hipLaunchKernelGGL(k<OP>, dim3(256 * waves), dim3(256), 0, 0, d, iters, 1.0f);
     hipDeviceSynchronize();
@@ -71,5 +99,7 @@ void run(const char* name) {
 int main() {
   run<0>("v_fma_f32"); run<1>("v_pk_fma_f32"); run<2>("v_exp_f32"); run<3>("v_max3_f32"); run<4>("v_cvt_pk_bf16_f32");
   run<5>("v_add_f32 (dep chain)"); run<6>("v_pk_mul_f32");
+  run<7>("v_pk_fma_f16"); run<8>("v_pk_add_u16"); run<9>("v_pk_lshlrev_b16"); run<10>("v_cvt_pkrtz_f16_f32"); run<11>("v_exp_f16");
+  run<12>("v_ldexp_f32"); run<13>("v_perm_b32");
   return 0;
 }
