@@ -6,7 +6,7 @@
         bench.py --gpus N --steps K --warmup W                       # N > 1: one rank per GPU over RCCL
 
 A "step" is one optimizer step over the fixed GLOBAL batch (default 256 volumes, BASELINE config 3): every rank runs
-global_batch / N volumes as micro-batches (default 32) with gradient accumulation, the flat-arena all-reduce overlaps the
+global_batch / N volumes as micro-batches (default min(64, global_batch / N)) with gradient accumulation, the flat-arena all-reduce overlaps the
 last micro-batch's backward, then grad-norm + fused AdamW.  Strong scaling: total work per step is fixed.
 Inputs are synthetic fp32 volumes already resident in HBM; weights are the reference's random init; masking noise comes
 from the device RNG inside the timed region.  Rank 0 prints ONE JSON line.
@@ -53,20 +53,23 @@ def cpu_baseline(max_seconds_hint=60.0):
 _PMC_KERNEL = {"gemm_wgrad_epi5": "gemm256_kernel<true, true, 5, true>", "gemm_dgrad_epi0": "gemm256_kernel<true, false, 0, false>",
                "gemm_dgrad_epi4": "gemm256_kernel<true, false, 4, false>", "gemm_fwd_epi0": "gemm256_kernel<false, false, 0, false>",
                "gemm_fwd_epi2": "gemm256_kernel<false, false, 2, false>", "gemm_fwd_epi3": "gemm256_kernel<false, false, 3, false>",
-               "attn_fwd_hd32": "attn_fwd_kernel<32>", "attn_fwd_hd64": "attn_fwd_kernel<64>", "attn_bwd_dq_hd32": "attn_bwd_dq_kernel<32>",
-               "attn_bwd_dq_hd64": "attn_bwd_dq_kernel<64>", "attn_bwd_dkv_hd32": "attn_bwd_dkv_kernel<32>",
-               "attn_bwd_dkv_hd64": "attn_bwd_dkv_kernel<64>"}
+               "attn_fwd_hd32": "attn_fwd_kernel<32, true>", "attn_fwd_hd64": "attn_fwd_kernel<64, true>",
+               "attn_bwd_dq_hd32": "attn_bwd_dq_kernel<32>", "attn_bwd_dq_hd64": "attn_bwd_dq_kernel<64>",
+               "attn_bwd_dkv_hd32": "attn_bwd_dkv_kernel<32>", "attn_bwd_dkv_hd64": "attn_bwd_dkv_kernel<64>"}
 
 
 def pmc_traffic(kind, micro_batch):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/README.md):
-    (2 x FETCH_SIZE + WRITE_SIZE) x 1024, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM.  The profiler cannot wrap the
-    process it runs in, so this is the offline measurement of the same per-launch shapes (micro-batch 32); None otherwise."""
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (tools/collect_pmc_traffic.sh,
+    profiles/README.md): (2 x FETCH_SIZE + WRITE_SIZE) x 1024, FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM.  The
+    profiler cannot wrap the process it runs in, so this is the offline measurement of the same per-launch shapes; None when
+    the file was taken at another micro-batch (other shapes)."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    if micro_batch != 32 or not os.path.exists(path):
+    if not os.path.exists(path):
         return None
     try:
         t = json.load(open(path))
+        if int(t.get("_meta", {}).get("micro_batch", 32)) != micro_batch:
+            return None
         return t[_PMC_KERNEL[kind]]["hbm_bytes_per_launch_corrected"]
     except Exception:
         return None
@@ -78,7 +81,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--global-batch", type=int, default=256)
-    ap.add_argument("--micro-batch", type=int, default=32)
+    ap.add_argument("--micro-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--clip-grad", type=float, default=None)
