@@ -98,6 +98,22 @@ struct TileStage {
   }
 };
 
+// (query/key block, head, batch) of this workgroup.  The hardware hands consecutive linear block ids to the 8 XCDs round
+// robin, so with the plain (x, y, z) mapping the ~N/128 workgroups that share one (batch, head)'s K/V land on all 8 XCDs and
+// every XCD's L2 fetches those K/V separately (measured: 5.5x the algorithmic HBM bytes).  xcd_remap gives each XCD a
+// contiguous range of logical ids instead, i.e. whole (batch, head) groups.
+struct BlockCoord { int x, head, b; };
+__device__ __forceinline__ BlockCoord attn_block_coord() {
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int n = gx * gy * (int)gridDim.z;
+#ifdef ATT_NO_XCD_REMAP
+  const int lin = (int)(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z));
+#else
+  const int lin = xcd_remap((int)(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z)), n);
+#endif
+  return BlockCoord{lin % gx, (lin / gx) % gy, lin / (gx * gy)};
+}
+
 // ---- K/V tile ring filled by LDS-DMA -------------------------------------------------------------------------------
 // Tiles go global -> LDS directly (buffer_load_dwordx4 ... lds: no staging registers, no ds_write, no VALU) into an
 // NB-deep ring, NB-1 tiles ahead of their use.  The instruction is issued from inline asm on purpose: the compiler drains
@@ -207,12 +223,13 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 3)) void attn_fwd_
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
+  const BlockCoord bc = attn_block_coord();
+  const int head = bc.head, b = bc.b;
   const size_t rs = (size_t)3 * H * HD;
   const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)head * HD;
   const bf16_t* kb_ = qb + (size_t)H * HD;
   const bf16_t* vb_ = qb + (size_t)2 * H * HD;
-  const int q0 = blockIdx.x * 128 + wid * 32;
+  const int q0 = bc.x * 128 + wid * 32;
   const int qrow = q0 + r;
 
   constexpr bool ONES_SUM = (HD == 32);
@@ -432,12 +449,13 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DQ32 : 2)) void attn_bwd_d
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
+  const BlockCoord bc = attn_block_coord();
+  const int head = bc.head, b = bc.b;
   const size_t rs = (size_t)3 * H * HD;
   const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)head * HD;
   const bf16_t* kb_ = qb + (size_t)H * HD;
   const bf16_t* vb_ = qb + (size_t)2 * H * HD;
-  const int qrow = blockIdx.x * 128 + wid * 32 + r;
+  const int qrow = bc.x * 128 + wid * 32 + r;
   const size_t ostride = (size_t)H * HD;
   const float sc2 = scale * LOG2E;
 
@@ -554,14 +572,15 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DKV32 : 2)) void attn_bwd_
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
+  const BlockCoord bc = attn_block_coord();
+  const int head = bc.head, b = bc.b;
   const size_t rs = (size_t)3 * H * HD;
   const size_t ostride = (size_t)H * HD;
   const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)head * HD;
   const bf16_t* kb_ = qb + (size_t)H * HD;
   const bf16_t* vb_ = qb + (size_t)2 * H * HD;
   const bf16_t* dob = dout + (size_t)b * N * ostride + (size_t)head * HD;
-  const int krow = blockIdx.x * 128 + wid * 32 + r;
+  const int krow = bc.x * 128 + wid * 32 + r;
   const float sc2 = scale * LOG2E;
 
   bf16x8 kf[KS], vf[KS];
