@@ -193,10 +193,19 @@ def main():
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the GPU number must survive a host that cannot fit the oracle
                 out["cpu_baseline"] = {"value": None, "unit": "volumes/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio, which a pipe only sees when the buffer is flushed (at exit, i.e. AFTER
+        # anything Python printed): push it out first so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
