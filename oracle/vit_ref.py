@@ -247,3 +247,60 @@ def mae2d_forward_backward(P, imgs, cfg, mask_ratio=0.75, noise=None):
     loss.backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Pg.items()}
     return loss.detach(), pred.detach(), mask, ids_restore, grads
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# 2-D ViT (OCTCube/models_vit.py on timm 0.3.2's VisionTransformer; timm is un-vendored: PARITY UNPINNED beyond the Block /
+# PatchEmbed semantics shared with the 2-D MAE above, which IS pinned by mae2d_small.npz)
+# ----------------------------------------------------------------------------------------------------------------
+@dataclass
+class ViT2DConfig:
+    img_size: int = 224
+    patch_size: int = 16
+    in_chans: int = 3
+    num_classes: int = 512
+    embed_dim: int = 768
+    depth: int = 12
+    num_heads: int = 12
+    mlp_ratio: float = 4.0
+    global_pool: bool = True
+    ln_eps: float = 1e-6
+
+    @property
+    def num_patches(self):
+        return (self.img_size // self.patch_size) ** 2
+
+
+def vit2d_param_shapes(cfg: ViT2DConfig):
+    D, hid = cfg.embed_dim, int(cfg.embed_dim * cfg.mlp_ratio)
+    s = {"cls_token": (1, 1, D), "pos_embed": (1, cfg.num_patches + 1, D),
+         "patch_embed.proj.weight": (D, cfg.in_chans, cfg.patch_size, cfg.patch_size), "patch_embed.proj.bias": (D,)}
+    for i in range(cfg.depth):
+        p = f"blocks.{i}"
+        s.update({f"{p}.norm1.weight": (D,), f"{p}.norm1.bias": (D,), f"{p}.attn.qkv.weight": (3 * D, D), f"{p}.attn.qkv.bias": (3 * D,),
+                  f"{p}.attn.proj.weight": (D, D), f"{p}.attn.proj.bias": (D,), f"{p}.norm2.weight": (D,), f"{p}.norm2.bias": (D,),
+                  f"{p}.mlp.fc1.weight": (hid, D), f"{p}.mlp.fc1.bias": (hid,), f"{p}.mlp.fc2.weight": (D, hid), f"{p}.mlp.fc2.bias": (D,)})
+    nm = "fc_norm" if cfg.global_pool else "norm"
+    s.update({f"{nm}.weight": (D,), f"{nm}.bias": (D,), "head.weight": (cfg.num_classes, D), "head.bias": (cfg.num_classes,)})
+    return s
+
+
+def vit2d_forward(P, x, cfg: ViT2DConfig):
+    """models_vit.py:35-55 forward_features + head."""
+    y = F.conv2d(x, P["patch_embed.proj.weight"], P["patch_embed.proj.bias"], stride=cfg.patch_size).flatten(2).transpose(1, 2)
+    y = torch.cat((P["cls_token"].expand(y.shape[0], -1, -1), y), dim=1) + P["pos_embed"]
+    for i in range(cfg.depth):
+        y = timm_block(y, P, f"blocks.{i}", cfg.num_heads, cfg.ln_eps)
+    D = cfg.embed_dim
+    if cfg.global_pool:
+        out = F.layer_norm(y[:, 1:, :].mean(dim=1), (D,), P["fc_norm.weight"], P["fc_norm.bias"], cfg.ln_eps)
+    else:
+        out = F.layer_norm(y, (D,), P["norm.weight"], P["norm.bias"], cfg.ln_eps)[:, 0]
+    return F.linear(out, P["head.weight"], P["head.bias"])
+
+
+def clip_loss(image_features, enface_features, logit_scale):
+    """open_clip/loss.py:181-230, world_size 1, plain labels (pinned by tests/golden/coem_loss.npz through octcubem_amd.coem)."""
+    logits = logit_scale * image_features @ enface_features.T
+    labels = torch.arange(logits.shape[0])
+    return (F.cross_entropy(logits, labels) + F.cross_entropy(logits.T, labels)) / 2

@@ -1,0 +1,94 @@
+"""GPU: the 2-D ViT tower (octcubem_amd.models_vit) and one COEM contrastive step (3-D ST ViT tower + 2-D ViT tower,
+L2-normalised features, ClipLoss, backward through both towers, logit_scale clamp) against the CPU oracle.
+Tolerances: features rel-L2 <= 1e-2, loss <= 5e-3 relative, tower gradients rel-L2 <= 6e-2 (bf16 operands through two towers
+and a temperature of ~14 on the logits)."""
+import math
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from octcubem_amd import coem, models_vit, models_vit_st
+    from octcubem_amd import optim as foptim
+from oracle import vit_ref as V
+
+DEV = "cuda"
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().flatten().cpu(); b = torch.as_tensor(b).detach().double().flatten().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def towers():
+    c3 = V.ViTSTConfig(num_frames=6, t_patch_size=3, img_size=64, patch_size=16, in_chans=1, num_classes=64, embed_dim=128, depth=2,
+                       num_heads=2, global_pool=True)
+    c2 = V.ViT2DConfig(img_size=64, patch_size=16, in_chans=3, num_classes=64, embed_dim=128, depth=2, num_heads=2, global_pool=True)
+    P3 = V.init_from_shapes(V.vit_st_param_shapes(c3), seed=51)
+    P2 = V.init_from_shapes(V.vit2d_param_shapes(c2), seed=52)
+    kw = dict(mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6))
+    m3 = models_vit_st.VisionTransformer(num_frames=6, t_patch_size=3, img_size=64, patch_size=16, in_chans=1, num_classes=64, embed_dim=128,
+                                         depth=2, num_heads=2, sep_pos_embed=True, cls_embed=True, global_pool=True, dropout=0.0, **kw)
+    m2 = models_vit.VisionTransformer(img_size=64, patch_size=16, in_chans=3, num_classes=64, embed_dim=128, depth=2, num_heads=2,
+                                      qkv_bias=True, global_pool=True, **kw)
+    assert set(m2.state_dict()) == set(P2)
+    m3.load_state_dict(P3, strict=True); m2.load_state_dict(P2, strict=True)
+    return c3, c2, P3, P2, m3.to(DEV), m2.to(DEV)
+
+
+def test_vit2d_tower_matches_oracle():
+    _, c2, _, P2, _, m2 = towers()
+    x = torch.randn(3, 3, 64, 64, generator=torch.Generator().manual_seed(1))
+    ref = V.vit2d_forward(P2, x, c2)
+    assert rel(m2.eval()(x.to(DEV)), ref) <= 1e-2
+    c_cls = V.ViT2DConfig(**{**c2.__dict__, "global_pool": False})
+    Pc = V.init_from_shapes(V.vit2d_param_shapes(c_cls), seed=53)
+    mc = models_vit.VisionTransformer(img_size=64, patch_size=16, in_chans=3, num_classes=64, embed_dim=128, depth=2, num_heads=2,
+                                      qkv_bias=True, global_pool=False, mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6))
+    mc.load_state_dict(Pc, strict=True)
+    assert rel(mc.to(DEV).eval()(x.to(DEV)), V.vit2d_forward(Pc, x, c_cls)) <= 1e-2
+
+
+def test_coem_contrastive_step_matches_oracle():
+    c3, c2, P3, P2, m3, m2 = towers()
+    model = coem.CustomTextCLIP(m3, m2).to(DEV).train()
+    g = torch.Generator().manual_seed(2)
+    vol = torch.rand(4, 1, 6, 64, 64, generator=g)
+    ir = torch.randn(4, 3, 64, 64, generator=g)
+    assert abs(float(model.logit_scale) - math.log(1 / 0.07)) < 1e-6
+    fi, ft, ls = model(vol.to(DEV), ir.to(DEV))
+    loss = coem.ClipLoss()(fi, ft, ls)
+    loss.backward()
+    # oracle
+    Q3 = {k: v.clone().requires_grad_(True) for k, v in P3.items()}
+    Q2 = {k: v.clone().requires_grad_(True) for k, v in P2.items()}
+    lsr = torch.tensor(math.log(1 / 0.07), requires_grad=True)
+    f3, _ = V.vit_st_forward(Q3, vol, c3)
+    f3 = torch.nn.functional.normalize(f3, dim=-1)
+    f2 = torch.nn.functional.normalize(V.vit2d_forward(Q2, ir, c2), dim=-1)
+    lr = V.clip_loss(f3, f2, lsr.exp())
+    lr.backward()
+    assert rel(fi, f3) <= 1e-2 and rel(ft, f2) <= 1e-2 and abs(float(ls) - float(lsr.exp())) < 1e-4
+    assert abs(float(loss) - float(lr)) <= 5e-3 * float(lr), (float(loss), float(lr))
+    assert abs(float(model.logit_scale.grad) - float(lsr.grad)) <= 5e-2 * abs(float(lsr.grad)) + 1e-4
+    for mod, Q in ((m3, Q3), (m2, Q2)):
+        tot = math.sqrt(sum(float(v.grad.double().norm()) ** 2 for v in Q.values() if v.grad is not None))
+        for k, p in mod.named_parameters():
+            gr = Q[k].grad
+            if gr is None or float(gr.norm()) < 1e-3 * tot or k.endswith("attn.k.bias"):
+                continue
+            assert rel(p.grad, gr) <= 6e-2, (k, rel(p.grad, gr))
+    # one optimizer step per parameter set + the temperature clamp
+    opts = [foptim.FusedAdamW(m3.parameters(), lr=1e-3), foptim.FusedAdamW(m2.parameters(), lr=1e-3),
+            torch.optim.AdamW([model.logit_scale], lr=1.0)]
+    l2 = coem.train_step(model, coem.ClipLoss(), vol.to(DEV), ir.to(DEV), opts)
+    assert abs(float(l2) - float(lr)) <= 5e-3 * float(lr)
+    assert 0.0 <= float(model.logit_scale) <= math.log(100) + 1e-6
+    with torch.no_grad():
+        model.logit_scale.fill_(10.0)
+    coem.clamp_logit_scale(model)
+    assert abs(float(model.logit_scale) - math.log(100)) < 1e-6
