@@ -40,7 +40,7 @@ int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2, const floa
 
 /* Stochastic depth (timm DropPath around both Block branches, video_vit.py:181-184 with drop_path > 0; fine-tune drivers use
  * 0.1-0.2): out f32 [M][N] = res + rowscale[m / rows_per_scale] * (X[M][K] @ W[N][K]^T + bias) -- the per-sample keep mask
- * (0 or 1/keep_prob) applied to the branch inside the residual epilogue.  nn.Linear layouts; small_tile as bit 8 above. */
+ * (0 or 1/keep_prob) applied to the branch inside the residual epilogue.  nn.Linear layouts; small_tile: the kernel-selection bits of `epilogue` above (0x100 / 0x200 / 0x400), 0 = automatic. */
 int octmae_linear_resid_rowscale(const void* W, const void* X, float* out, const float* bias, const float* res,
                                  const float* rowscale, int rows_per_scale, int N, int M, int K, int ldw, int ldx, int ldout,
                                  int ldres, int small_tile, void* stream);

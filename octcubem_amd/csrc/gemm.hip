@@ -469,14 +469,208 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const GemmParams p) {
   }
 }
 
+// =====================================================================================================
+// Phased main loop for the same 256 x 256 x 64 tile (cdna_hip_programming.md section 5, "8-phase" structure, re-derived for
+// 32x32x16 MFMAs and this kernel's operand layouts).  A k-tile is computed in 4 phases, one quadrant (64 a x 32 b) of the
+// wave's 128 x 64 block per phase over the full K = 64 (8 MFMAs); a phase is [LDS-read segment | barrier | MFMA segment |
+// barrier].  Waves 4-7 -- the SIMD partners of waves 0-3 -- run ONE barrier behind, so on every SIMD one wave's MFMA
+// segment runs beside its partner's LDS-read segment: the matrix pipe never waits for fragment reads.  Fragments are
+// reused across phases (A: quadrant rows loaded in phases 1 and 3; B: both column blocks kept), 24 reads per k-tile as before.
+//   phase 1: read A[q0], B[q0]   stage A halves of k-tile t+1     MFMA (q0, q0)
+//   phase 2: read B[q1]                                            MFMA (q0, q1)
+//   phase 3: read A[q1]                                            MFMA (q1, q1)
+//   phase 4:                     stage B halves of k-tile t+2     MFMA (q1, q0)     s_waitcnt vmcnt(4) before its barrier
+// Operand tiles are four 16 KiB half-images per stage (A rows 0-127 / 128-255, B likewise), staged by LDS-DMA from inline
+// asm (untracked: the only vmcnt waits are the counted ones), each half one phase-set AFTER its last reader has passed a
+// barrier: A halves die in phase 3, B halves in phase 2.  The B halves are therefore prefetched a whole k-tile ahead and
+// the A halves three phases ahead; only the 4 youngest loads are in flight across the phase-4 barrier.
+// =====================================================================================================
+typedef __attribute__((ext_vector_type(4))) int gi32x4;
+
+__device__ __forceinline__ int kcH_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }          // [128 rows][64 k]
+__device__ __forceinline__ int ksH_off(int kr, int c) { return kr * 256 + ((c ^ ((kr & 3) << 2)) << 4); }         // [64 k][128 rows]
+
+// fragment of 32 rows starting at in-half row rb, k-step s, from one 16 KiB half-image
+template <bool KS>
+__device__ __forceinline__ bf16x8 read_fragH(const char* lds, int rb, int s, int lane) {
+  if (!KS) {
+    const int r = rb + (lane & 31), c = 2 * s + (lane >> 5);
+    return *reinterpret_cast<const bf16x8*>(lds + kcH_off(r, c));
+  } else {
+    const int h = lane >> 5, gi = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
+    const int c = (rb >> 3) + 2 * gi + (pp >> 1);
+    const int kr0 = 16 * s + 8 * h + q;
+    const bf16x4 lo = lds_tr_read(lds + ksH_off(kr0, c) + (pp & 1) * 8);
+    const bf16x4 hi = lds_tr_read(lds + ksH_off(kr0 + 4, c) + (pp & 1) * 8);
+    return cat4(lo, hi);
+  }
+}
+
+__device__ __forceinline__ void glds16(const gi32x4& rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // m0 is "reserved"; nothing else in this kernel lives in it
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+#pragma clang diagnostic pop
+}
+
 template <bool A_KS, bool B_KS, int EPI, bool OUT_AB>
-static int launch256(const GemmParams& p, int splitk, hipStream_t st) {
-  auto kern = gemm256_kernel<A_KS, B_KS, EPI, OUT_AB>;
-  static bool attr_set = false;
-  if (!attr_set) {
+__global__ __launch_bounds__(512, 1) void gemm256p_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [stage 2][operand 2][half 2] x 16 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wa = wid >> 2, wb = wid & 3;          // wa = 1: the late group (waves 4-7)
+
+  const int nt = p.tiles_a * p.tiles_b;
+  const int t = xcd_remap(blockIdx.x, nt);
+  const int tb = t / p.tiles_a, ta = t - tb * p.tiles_a;
+  const int a0 = ta * T2, b0 = tb * T2;
+
+  const int kt0 = blockIdx.z * p.ktiles_per_split;
+  int kt1 = kt0 + p.ktiles_per_split;
+  if (kt1 > p.ktiles) kt1 = p.ktiles;
+  const int nk = kt1 - kt0;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nk > 0) {
+    const unsigned a_bytes = (unsigned)((size_t)(A_KS ? p.K : p.NA) * p.lda * 2);
+    const unsigned b_bytes = (unsigned)((size_t)(B_KS ? p.K : p.NB) * p.ldb * 2);
+    const unsigned long long pa = (unsigned long long)p.A, pb = (unsigned long long)p.B;
+    const gi32x4 ra = {(int)(unsigned)pa, (int)(unsigned)(pa >> 32), (int)a_bytes, 0x00020000};
+    const gi32x4 rb = {(int)(unsigned)pb, (int)(unsigned)(pb >> 32), (int)b_bytes, 0x00020000};
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    // per-lane source offsets of this wave's two 1-KiB pieces of each half-image (k-tile 0), and the k-tile stride
+    unsigned va[2][2], vb[2][2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int j = 2 * wid + n;
+        if (!A_KS) {
+          const int r = 8 * j + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+          va[hf][n] = (unsigned)(((size_t)(a0 + hf * 128 + r) * p.lda + (size_t)kt0 * TK + c * 8) * 2);
+        } else {
+          const int kr = 4 * j + (lane >> 4), c = (lane & 15) ^ ((kr & 3) << 2);
+          va[hf][n] = (unsigned)((((size_t)kt0 * TK + kr) * p.lda + a0 + hf * 128 + c * 8) * 2);
+        }
+        if (!B_KS) {
+          const int r = 8 * j + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+          vb[hf][n] = (unsigned)(((size_t)(b0 + hf * 128 + r) * p.ldb + (size_t)kt0 * TK + c * 8) * 2);
+        } else {
+          const int kr = 4 * j + (lane >> 4), c = (lane & 15) ^ ((kr & 3) << 2);
+          vb[hf][n] = (unsigned)((((size_t)kt0 * TK + kr) * p.ldb + b0 + hf * 128 + c * 8) * 2);
+        }
+      }
+    const unsigned ka = (unsigned)(A_KS ? (size_t)TK * p.lda * 2 : (size_t)TK * 2);
+    const unsigned kb = (unsigned)(B_KS ? (size_t)TK * p.ldb * 2 : (size_t)TK * 2);
+    auto stage = [&](int op, int kt, int buf) {            // both halves of operand `op` of k-tile kt -> stage buf (4 loads)
+      const unsigned base = lds0 + (unsigned)(buf * 65536 + op * 32768 + 2 * wid * 1024);
+      const unsigned so = (unsigned)kt * (op ? kb : ka);
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          glds16(op ? rb : ra, base + (unsigned)(hf * 16384 + n * 1024), op ? vb[hf][n] : va[hf][n], so);
+    };
+    // prologue: B(0), A(0), B(1) -- the order the loop keeps (B a k-tile ahead of A)
+    stage(1, 0, 0);
+    stage(0, 0, 0);
+    stage(1, 1, 1);
+    __builtin_amdgcn_s_waitcnt(0x0F74);       // vmcnt(4) (lgkmcnt/expcnt untouched): A(0), B(0) have landed
+    __builtin_amdgcn_s_barrier();
+    if (wa) __builtin_amdgcn_s_barrier();     // the late group starts one barrier behind
+
+    const int rowB = (wb & 1) * 64;           // this wave's 64 b-rows inside its B half
+    bf16x8 fa[2][4], fb[2][4];
+    for (int it = 0; it < nk; ++it) {
+      const int buf = it & 1;
+      const char* cA = smem + buf * 65536 + wa * 16384;                    // my A half: rows wa*128 ..
+      const char* cB = smem + buf * 65536 + 32768 + (wb >> 1) * 16384;     // my B half
+      // ---- phase 1
+#pragma unroll
+      for (int s = 0; s < 4; ++s) fb[0][s] = read_fragH<B_KS>(cB, rowB, s, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fa[i][s] = read_fragH<A_KS>(cA, i * 32, s, lane);
+      stage(0, it + 1, buf ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][0] = mfma32(fa[i][s], fb[0][s], acc[i][0]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // ---- phase 2
+#pragma unroll
+      for (int s = 0; s < 4; ++s) fb[1][s] = read_fragH<B_KS>(cB, rowB + 32, s, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][1] = mfma32(fa[i][s], fb[1][s], acc[i][1]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // ---- phase 3
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fa[i][s] = read_fragH<A_KS>(cA, 64 + i * 32, s, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[2 + i][1] = mfma32(fa[i][s], fb[1][s], acc[2 + i][1]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // ---- phase 4
+      stage(1, it + 2, buf);
+      __builtin_amdgcn_s_waitcnt(0x0F74);     // vmcnt(4): everything but the B halves just issued -- A(it+1), B(it+1) landed
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[2 + i][0] = mfma32(fa[i][s], fb[0][s], acc[2 + i][0]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    }
+    if (!wa) __builtin_amdgcn_s_barrier();    // the early group waits for the late one
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the trailing (unused) prefetches must not land in the epilogue's LDS
+    __builtin_amdgcn_s_barrier();
+  }
+  if (OUT_AB || (p.NA & 7) != 0) {
+    gemm_epilogue<EPI, OUT_AB, 4, 2>(p, acc, a0 + wa * 128, b0 + wb * 64, lane, gridDim.z > 1);
+  } else {
+    gemm_epilogue_lds<EPI>(p, acc, a0 + wa * 128, b0 + wb * 64, lane, smem + wid * 16384);
+  }
+}
+
+template <bool A_KS, bool B_KS, int EPI, bool OUT_AB>
+static int launch256(const GemmParams& p, int splitk, hipStream_t st, bool phased) {
+  auto kern = phased ? gemm256p_kernel<A_KS, B_KS, EPI, OUT_AB> : gemm256_kernel<A_KS, B_KS, EPI, OUT_AB>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[phased]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set[phased] = true;
   }
   dim3 grid(p.tiles_a * p.tiles_b, 1, splitk);
   hipLaunchKernelGGL(kern, grid, dim3(512), 4 * TILE2_BYTES, st, p);
@@ -507,8 +701,13 @@ using namespace octmae;
 static int gemm_impl(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
                      int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided,
                      int b_kstrided, int epilogue, int splitk, void* stream, const float* rowscale, int rows_per_scale) {
-  // bit 8 of `epilogue` forces the 128-tile kernel (tests exercise both tile shapes on the same problem)
+  // bit 8 of `epilogue` forces the 128-tile kernel, bit 9 the two-stage (un-phased) 256-tile main loop: tests and A/B runs
+  // exercise every kernel on the same problem
   const int variant = (epilogue >> 8) & 1;
+  // phased main loop by default whenever an operand is k-strided (dgrad, wgrad: +10..25 %); with two k-contiguous operands
+  // (forward) the plain two-stage loop is as fast at K = 4096 and 12 % faster at K = 1024 (shorter pipeline fill).
+  // bit 9 forces the two-stage loop, bit 10 the phased one.
+  const bool phased = ((epilogue >> 10) & 1) ? true : ((epilogue >> 9) & 1) ? false : (a_kstrided || b_kstrided);
   epilogue &= 0xff;
   OCTMAE_CHECK_ARG(A && B && C);
   OCTMAE_CHECK_ARG(NA > 0 && NB > 0 && K > 0);
@@ -546,7 +745,7 @@ static int gemm_impl(const void* A, const void* B, void* C, void* C2, const floa
 
 #define OCTMAE_GEMM_CASE(AKS, BKS, E, AB)                                  \
   if (a_kstrided == AKS && b_kstrided == BKS && epilogue == E)             \
-    return big ? launch256<AKS, BKS, E, AB>(p, splitk, st) : launch<AKS, BKS, E, AB>(p, splitk, st);
+    return big ? launch256<AKS, BKS, E, AB>(p, splitk, st, phased) : launch<AKS, BKS, E, AB>(p, splitk, st);
   // forward linears (nn.Linear layout both sides)
   OCTMAE_GEMM_CASE(0, 0, EPI_BF16, false)
   OCTMAE_GEMM_CASE(0, 0, EPI_F32, false)
@@ -573,6 +772,6 @@ extern "C" int octmae_linear_resid_rowscale(const void* W, const void* X, float*
                                             const float* rowscale, int rows_per_scale, int N, int M, int K, int ldw, int ldx,
                                             int ldout, int ldres, int small_tile, void* stream) {
   OCTMAE_CHECK_ARG(rowscale != nullptr && rows_per_scale > 0);
-  return gemm_impl(W, X, out, nullptr, bias, res, N, M, K, ldw, ldx, ldout, ldres, 0, 0, EPI_RESID | (small_tile ? 0x100 : 0), 1,
+  return gemm_impl(W, X, out, nullptr, bias, res, N, M, K, ldw, ldx, ldout, ldres, 0, 0, EPI_RESID | (small_tile & 0x700), 1,
                    stream, rowscale, rows_per_scale);
 }

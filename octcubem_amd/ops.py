@@ -149,11 +149,17 @@ _GEMM_KIND = {(0, 0): "gemm_fwd", (1, 0): "gemm_dgrad", (1, 1): "gemm_wgrad"}
 
 
 FORCE_SMALL_TILE = False    # tests: route every GEMM through the 128-tile register-staged kernel
+FORCE_TWO_STAGE = False     # tests / A-B: the un-phased two-stage main loop of the 256-tile kernel
+FORCE_PHASED = False        # tests / A-B: the phased main loop also where the two-stage one is the default
+
+
+def _variant_bits():
+    return (0x100 if FORCE_SMALL_TILE else 0) | (0x200 if FORCE_TWO_STAGE else 0) | (0x400 if FORCE_PHASED else 0)
 
 
 def _gemm(A, B, C, NA, NB, K, lda, ldb, ldc, a_ks, b_ks, epi, C2=None, bias=None, aux=None, ldaux=0, splitk=1):
     args = (A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(C2), _p(bias), _p(aux), NA, NB, K, lda, ldb, ldc, ldaux, a_ks, b_ks,
-            epi | (0x100 if FORCE_SMALL_TILE else 0), splitk, _stream())
+            epi | _variant_bits(), splitk, _stream())
     if KTIMER is None:
         call("octmae_gemm_bf16", *args)
     else:
@@ -173,7 +179,7 @@ def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], m
         assert mode == "resid" and rowscale.dtype == F32 and rowscale.numel() * rows_per_scale == M
         out = torch.empty((M, N), dtype=F32, device=dev)
         args = (w.data_ptr(), x.data_ptr(), out.data_ptr(), _p(bias), res.data_ptr(), rowscale.data_ptr(), rows_per_scale, N, M, K,
-                w.stride(0), x.stride(0), N, res.stride(0), 1 if FORCE_SMALL_TILE else 0, _stream())
+                w.stride(0), x.stride(0), N, res.stride(0), _variant_bits(), _stream())
         _launch(f"gemm_fwd_epi{EPI_RESID}", 2.0 * N * M * K, 2.0 * (N * K + M * K) + 8.0 * N * M,
                 lambda: call("octmae_linear_resid_rowscale", *args))
         return out

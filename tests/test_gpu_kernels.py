@@ -76,13 +76,17 @@ GEMM_SHAPES = [(128, 128, 64), (256, 384, 128), (200, 136, 72), (1281, 384, 128)
                (600, 512, 256), (2000, 1024, 1024), (3000, 512, 256), (2562, 768, 512)]
 
 
-@pytest.fixture(params=["auto", "tile128"])
+@pytest.fixture(params=["auto", "tile128", "twostage", "phased"])
 def tile_variant(request):
-    """Every GEMM problem runs through the automatic choice (256-tile LDS-DMA kernel when it fits) and through the
-    128-tile register-staged kernel."""
+    """Every GEMM problem runs through the automatic choice (256-tile LDS-DMA kernel with the phased main loop when it fits),
+    through the 128-tile register-staged kernel, and through both main loops of the 256-tile kernel (two-stage, phased)."""
     ops.FORCE_SMALL_TILE = request.param == "tile128"
+    ops.FORCE_TWO_STAGE = request.param == "twostage"
+    ops.FORCE_PHASED = request.param == "phased"
     yield request.param
     ops.FORCE_SMALL_TILE = False
+    ops.FORCE_TWO_STAGE = False
+    ops.FORCE_PHASED = False
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
