@@ -30,7 +30,8 @@ int octmae_abi_version(void);
  *   1  C f32  = X + bias[a]                       decoder_pred             models_mae_joint_res_flash_attn.py:595
  *   2  C bf16 = X + bias, C2 bf16 = gelu(C)       Mlp fc1 + nn.GELU        video_vit.py:174-179 (timm Mlp)
  *   3  C f32  = aux_f32[b][a] + X + bias[a]       proj / fc2 + residual    video_vit.py:182-183
- *   4  C bf16 = X * gelu'(aux_bf16[b][a])         backward of 2 (dgrad of fc2 fused with GELU')
+ *   4  C bf16 = X * gelu'(aux_bf16[b][a])         backward of 2 (dgrad of fc2 fused with GELU'); a non-NULL C2 is an fp32 [NA]
+ *                                                 vector that receives += the column sums of C (fc1's bias gradient)
  *   5  C f32[a][b] += X  (NA rows x NB columns; split-K over `splitk` workgroup slices, fp32 atomics
  *                         when splitk > 1)        weight gradients (autograd of nn.Linear)
  * bias may be NULL.  Requirements: lda, ldb multiples of 8; NA multiple of 4 (epilogues 0-4). */

@@ -348,6 +348,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
       }
       __builtin_amdgcn_wave_barrier();
       bf16_t* out = reinterpret_cast<bf16_t*>(pass == 0 ? p.C : p.C2);
+      float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // EPI_DGELU: column sums of what is stored (the fc1 bias gradient)
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
         const int row = it * 4 + rrow;
@@ -358,8 +359,23 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
             const u32x4 pre = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.aux) + (size_t)b * p.ldaux + a);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = pack2bf(bflo(v[e]) * dgelu_f(bflo(pre[e])), bfhi(v[e]) * dgelu_f(bfhi(pre[e])));
+            if (p.C2 != nullptr) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { cs[2 * e] += bflo(v[e]); cs[2 * e + 1] += bfhi(v[e]); }
+            }
           }
           *reinterpret_cast<u32x4*>(out + (size_t)b * p.ldc + a) = v;
+        }
+      }
+      if (EPI == EPI_DGELU && p.C2 != nullptr) {      // 4 row groups (lane >> 4) hold partial sums of the same 8 columns
+        float* colsum = reinterpret_cast<float*>(p.C2);
+        const int a = a_base + rc * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = cs[e];
+          t += __shfl_xor(t, 16, 64);
+          t += __shfl_xor(t, 32, 64);
+          if (rrow == 0 && a < p.NA) unsafeAtomicAdd(colsum + a + e, t);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -697,6 +713,8 @@ static int launch(const GemmParams& p, int splitk, hipStream_t st) {
 
 using namespace octmae;
 
+extern "C" int octmae_colsum_accum(const void* in, int in_is_bf16, float* out, int M, int N, int ld, void* stream);
+
 // C[b][a] (+epilogue) = sum_k A[a][k] B[b][k];  see include/octmae.h for the contract.
 static int gemm_impl(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
                      int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided,
@@ -743,9 +761,18 @@ static int gemm_impl(const void* A, const void* B, void* C, void* C2, const floa
   p.ktiles_per_split = (p.ktiles + splitk - 1) / splitk;
   splitk = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
 
+  // EPI_DGELU with C2: C2 is an fp32 [NA] vector that receives += the column sums of C (bias gradient of the Linear whose
+  // activation is being differentiated).  Fused into the 256-tile epilogue; the 128-tile kernel is followed by the
+  // stand-alone column-sum kernel.
+  float* dgelu_colsum = (epilogue == EPI_DGELU) ? reinterpret_cast<float*>(C2) : nullptr;
+  if (epilogue == EPI_DGELU && !(big && (NA & 7) == 0)) p.C2 = nullptr;
 #define OCTMAE_GEMM_CASE(AKS, BKS, E, AB)                                  \
-  if (a_kstrided == AKS && b_kstrided == BKS && epilogue == E)             \
-    return big ? launch256<AKS, BKS, E, AB>(p, splitk, st, phased) : launch<AKS, BKS, E, AB>(p, splitk, st);
+  if (a_kstrided == AKS && b_kstrided == BKS && epilogue == E) {           \
+    int rc_ = big ? launch256<AKS, BKS, E, AB>(p, splitk, st, phased) : launch<AKS, BKS, E, AB>(p, splitk, st);          \
+    if (rc_ == 0 && E == EPI_DGELU && dgelu_colsum != nullptr && p.C2 == nullptr)                                       \
+      rc_ = octmae_colsum_accum(C, 1, dgelu_colsum, NB, NA, ldc, stream);                                                \
+    return rc_;                                                                                                           \
+  }
   // forward linears (nn.Linear layout both sides)
   OCTMAE_GEMM_CASE(0, 0, EPI_BF16, false)
   OCTMAE_GEMM_CASE(0, 0, EPI_F32, false)

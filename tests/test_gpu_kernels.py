@@ -134,6 +134,11 @@ def test_gemm_dgrad_and_wgrad(M, N, K, tile_variant):
     torch.nn.functional.gelu(xg).backward(dx_ref)
     dxg = ops.linear_dgrad(dy, w, pre=pre)
     assert rel(dxg, xg.grad) < 3e-3
+    cs0 = torch.randn(K, generator=g).to(DEV)                # fused column sums (fc1 bias gradient) accumulate into a vector
+    cs = cs0.clone()
+    dxg2 = ops.linear_dgrad(dy, w, pre=pre, colsum=cs)
+    assert torch.equal(dxg2, dxg)
+    assert rel(cs, cs0.double() + dxg.double().sum(0)) < 2e-5
     gw0 = torch.randn(N, K, generator=g).to(DEV)
     gw = gw0.clone()
     ops.linear_wgrad_accum(dy, x, gw)
