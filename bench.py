@@ -50,12 +50,15 @@ def cpu_baseline(max_seconds_hint=60.0):
             "sample": f"1 volume (1x60x256x256) forward+backward, fp32, torch CPU {cores} threads, {dt:.1f} s, loss {float(loss):.4f}"}
 
 
-_PMC_KERNEL = {"gemm_wgrad_epi5": "gemm256_kernel<true, true, 5, true>", "gemm_dgrad_epi0": "gemm256_kernel<true, false, 0, false>",
-               "gemm_dgrad_epi4": "gemm256_kernel<true, false, 4, false>", "gemm_fwd_epi0": "gemm256_kernel<false, false, 0, false>",
-               "gemm_fwd_epi2": "gemm256_kernel<false, false, 2, false>", "gemm_fwd_epi3": "gemm256_kernel<false, false, 3, false>",
-               "attn_fwd_hd32": "attn_fwd_kernel<32, true>", "attn_fwd_hd64": "attn_fwd_kernel<64, true>",
-               "attn_bwd_dq_hd32": "attn_bwd_dq_kernel<32>", "attn_bwd_dq_hd64": "attn_bwd_dq_kernel<64>",
-               "attn_bwd_dkv_hd32": "attn_bwd_dkv_kernel<32>", "attn_bwd_dkv_hd64": "attn_bwd_dkv_kernel<64>"}
+# bench kernel kind -> kernel name(s) in the PMC file (k-strided operands run the phased main loop, gemm256p_kernel)
+_PMC_KERNEL = {"gemm_wgrad_epi5": ["gemm256p_kernel<true, true, 5, true>", "gemm256_kernel<true, true, 5, true>"],
+               "gemm_dgrad_epi0": ["gemm256p_kernel<true, false, 0, false>", "gemm256_kernel<true, false, 0, false>"],
+               "gemm_dgrad_epi4": ["gemm256p_kernel<true, false, 4, false>", "gemm256_kernel<true, false, 4, false>"],
+               "gemm_fwd_epi0": ["gemm256_kernel<false, false, 0, false>"], "gemm_fwd_epi2": ["gemm256_kernel<false, false, 2, false>"],
+               "gemm_fwd_epi3": ["gemm256_kernel<false, false, 3, false>"],
+               "attn_fwd_hd32": ["attn_fwd_kernel<32, true>"], "attn_fwd_hd64": ["attn_fwd_kernel<64, true>"],
+               "attn_bwd_dq_hd32": ["attn_bwd_dq_kernel<32>"], "attn_bwd_dq_hd64": ["attn_bwd_dq_kernel<64>"],
+               "attn_bwd_dkv_hd32": ["attn_bwd_dkv_kernel<32>"], "attn_bwd_dkv_hd64": ["attn_bwd_dkv_kernel<64>"]}
 
 
 def pmc_traffic(kind, micro_batch):
@@ -70,7 +73,10 @@ def pmc_traffic(kind, micro_batch):
         t = json.load(open(path))
         if int(t.get("_meta", {}).get("micro_batch", 32)) != micro_batch:
             return None
-        return t[_PMC_KERNEL[kind]]["hbm_bytes_per_launch_corrected"]
+        for name in _PMC_KERNEL[kind]:
+            if name in t:
+                return t[name]["hbm_bytes_per_launch_corrected"]
+        return None
     except Exception:
         return None
 
