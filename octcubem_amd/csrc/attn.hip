@@ -29,6 +29,9 @@ namespace octmae {
 #ifndef ATT_OCC_FWD32
 #define ATT_OCC_FWD32 3
 #endif
+#ifndef ATT_OCC_FWD64
+#define ATT_OCC_FWD64 3
+#endif
 #ifndef ATT_OCC_DQ32
 #define ATT_OCC_DQ32 3
 #endif
@@ -212,7 +215,7 @@ __device__ __forceinline__ bf16x8 scale_frag(u32x4 v, float s) {
 // work, the limiter of this kernel: no max chain, no rescale, and the score accumulators start from the inline constant 0
 // (no per-tile broadcast of -max): per score only v_exp_f32 + v_cvt_pk remain.
 template <int HD, bool FAST>
-__global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : 3)) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+__global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : ATT_OCC_FWD64)) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                           float* __restrict__ lse, int N, int H, float scale, int* __restrict__ flag) {
   if (!FAST && flag != nullptr && *flag == 0) return;   // safe kernel: only runs when the optimistic one gave up
   constexpr int KS = HD / 16;   // k-steps over the head dimension
