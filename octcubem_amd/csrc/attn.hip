@@ -14,8 +14,9 @@
 //                                    tile in LDS through ds_read_b64_tr_b16.
 // Backward is two deterministic kernels (no atomics): dQ walks key tiles with the same orientation; dK/dV
 // keeps the KEY on the lane and walks query tiles, so dK^T/dV^T accumulate in registers.
-// K/V (or Q/dO) tiles are 64 rows, register-staged, double-buffered in LDS with one barrier per tile; the
-// XOR swizzle makes both the ds_read_b128 row reads and the transposed reads bank-conflict-free.
+// K/V (or Q/dO) tiles are 64 rows and arrive by LDS-DMA in a 3-4 deep ring (TileDma below), one barrier per tile behind a
+// counted s_waitcnt; the XOR swizzle (applied to the DMA's SOURCE address) makes both the ds_read_b128 row reads and the
+// transposed reads bank-conflict-free.  Workgroups are mapped XCD-aware (attn_block_coord).
 #include <type_traits>
 
 #include "common.hpp"
@@ -74,30 +75,6 @@ struct Tile {  // 64 rows x HD bf16, row-major, XOR-swizzled 16-byte chunks
     const bf16x4 lo = lds_tr_read(t + off(r0, c) + (p & 1) * 8);
     const bf16x4 hi = lds_tr_read(t + off(r0 + 8, c) + (p & 1) * 8);
     return cat4(lo, hi);
-  }
-};
-
-// register-staged copy of a 64-row tile: rows row0.. of a [.., stride] bf16 matrix, rows >= nvalid zero-filled
-template <int HD>
-struct TileStage {
-  static constexpr int PER = (64 * HD / 8) / 256;  // 16-byte chunks per thread (2 for HD 64, 1 for HD 32)
-  u32x4 regs[PER];
-  __device__ __forceinline__ void issue(const bf16_t* base, size_t stride, int row0, int nvalid, int tid) {
-#pragma unroll
-    for (int n = 0; n < PER; ++n) {
-      const int q = tid + 256 * n;
-      const int r = q / Tile<HD>::CHUNKS, c = q % Tile<HD>::CHUNKS;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (row0 + r < nvalid) v = *reinterpret_cast<const u32x4*>(base + (size_t)(row0 + r) * stride + c * 8);
-      regs[n] = v;
-    }
-  }
-  __device__ __forceinline__ void commit(char* lds, int tid) const {
-#pragma unroll
-    for (int n = 0; n < PER; ++n) {
-      const int q = tid + 256 * n;
-      *reinterpret_cast<u32x4*>(lds + Tile<HD>::off(q / Tile<HD>::CHUNKS, q % Tile<HD>::CHUNKS)) = regs[n];
-    }
   }
 };
 
