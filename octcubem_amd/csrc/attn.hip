@@ -337,6 +337,11 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : ATT_OCC_FWD64)) vo
 
   f32x16 sA[2], sB[2];
   qk(Kbuf, sA);
+  // S_0 is the only score tile computed outside a step: step 0 restages slot 0 of the K ring (K_NB) right away, so every
+  // wave's reads of K_0 must have returned first (found by tools/stress_attn_race.py: without this barrier 0.3 % of the
+  // decoder-shape launches differed in a few rows)
+  __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+  __builtin_amdgcn_s_barrier();
   int t = 0;
   if (ATT_PIPELINE(HD)) {
     for (; t + 2 < ntiles; t += 2) {
