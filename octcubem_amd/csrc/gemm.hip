@@ -320,6 +320,22 @@ __device__ __forceinline__ bf16x8 read_frag2(const char* lds, int rb, int s, int
 // No workgroup barrier: the region is private to the wave and LDS executes a wave's accesses in order.
 __device__ __forceinline__ int epi_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
 
+// Global accesses of this epilogue go through buffer descriptors that cover exactly the wave's <= 64 output rows: rows past
+// NB and columns past NA fall outside num_records (loads return 0, stores are dropped), so the whole epilogue is one
+// branch-free block.  That matters for the epilogues that READ (residual, pre-activation): with guarded plain loads LLVM
+// sinks every load into its store's branch, and a wave then makes 16-32 dependent HBM round trips with nothing else in
+// flight -- the fc2 / proj / dgelu GEMMs spent as long in the epilogue as in the k-loop.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* base, int b_base, int NB, int ld, int esize) {
+  int rows = NB - b_base;
+  rows = rows < 0 ? 0 : (rows > 64 ? 64 : rows);
+  const unsigned long long q = reinterpret_cast<unsigned long long>(base) + (unsigned long long)b_base * ld * esize;
+  // wave-uniform by construction; said explicitly so that the descriptor lives in SGPRs without a waterfall loop
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)q), hi = __builtin_amdgcn_readfirstlane((unsigned)(q >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                           __builtin_amdgcn_readfirstlane(rows * ld * esize), 0x00020000);
+}
+constexpr unsigned EPI_OOB = 0x7ffffff0u;   // byte offset past any num_records above: masks a lane whose columns are >= NA
+
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&acc)[4][2], int a_base, int b_base, int lane,
                                                   char* wl) {
@@ -328,15 +344,25 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
   if (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU) {
     // bf16 image [64 b][128 a].  EPI_DGELU multiplies by gelu'(pre) on the read side: the product of the bf16-rounded
     // dgrad with gelu' is rounded once more -- the numerics of an autocast GELU backward, which also reads a bf16 dgrad.
+    const int a = a_base + rc * 8;
+    const bool a_ok = a < p.NA;
+    const unsigned o_out = a_ok ? (unsigned)(rrow * p.ldc + a) * 2u : EPI_OOB;
+    u32x4 prev[16];
+    if (EPI == EPI_DGELU) {   // all 16 pre-activation row segments requested before the transpose
+      const __amdgpu_buffer_rsrc_t rx = epi_rsrc(p.aux, b_base, p.NB, p.ldaux, 2);
+      const unsigned o_aux = a_ok ? (unsigned)(rrow * p.ldaux + a) * 2u : EPI_OOB;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) prev[it] = __builtin_amdgcn_raw_buffer_load_b128(rx, o_aux + it * 4 * p.ldaux * 2, 0, 0);
+    }
 #pragma unroll
     for (int pass = 0; pass < (EPI == EPI_GELU ? 2 : 1); ++pass) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int a = a_base + i * 32 + 8 * g + 4 * h;
+          const int aw = a_base + i * 32 + 8 * g + 4 * h;
           f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-          if (EPI != EPI_DGELU && p.bias != nullptr && a < p.NA) bv = *reinterpret_cast<const f32x4*>(p.bias + a);
+          if (EPI != EPI_DGELU && p.bias != nullptr && aw < p.NA) bv = *reinterpret_cast<const f32x4*>(p.bias + aw);
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             u32x2 w = {pack2bf(acc[i][j][4 * g] + bv[0], acc[i][j][4 * g + 1] + bv[1]),
@@ -350,41 +376,74 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
         }
       }
       __builtin_amdgcn_wave_barrier();
-      bf16_t* out = reinterpret_cast<bf16_t*>(pass == 0 ? p.C : p.C2);
+      const __amdgpu_buffer_rsrc_t ro = epi_rsrc(pass == 0 ? p.C : p.C2, b_base, p.NB, p.ldc, 2);
       float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // EPI_DGELU: column sums of what is stored (the fc1 bias gradient)
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
         const int row = it * 4 + rrow;
         u32x4 v = *reinterpret_cast<const u32x4*>(wl + epi_off(row, rc));
-        const int b = b_base + row, a = a_base + rc * 8;
-        if (b < p.NB && a < p.NA) {
-          if (EPI == EPI_DGELU) {
-            const u32x4 pre = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.aux) + (size_t)b * p.ldaux + a);
+        if (EPI == EPI_DGELU) {
+          const u32x4 pre = prev[it];   // zeros outside the matrix: gelu'(0) * v is stored nowhere and summed nowhere
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = pack2bf(bflo(v[e]) * dgelu_f(bflo(pre[e])), bfhi(v[e]) * dgelu_f(bfhi(pre[e])));
-            if (p.C2 != nullptr) {
+          for (int e = 0; e < 4; ++e) v[e] = pack2bf(bflo(v[e]) * dgelu_f(bflo(pre[e])), bfhi(v[e]) * dgelu_f(bfhi(pre[e])));
+          if (p.C2 != nullptr && b_base + row < p.NB) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { cs[2 * e] += bflo(v[e]); cs[2 * e + 1] += bfhi(v[e]); }
-            }
+            for (int e = 0; e < 4; ++e) { cs[2 * e] += bflo(v[e]); cs[2 * e + 1] += bfhi(v[e]); }
           }
-          *reinterpret_cast<u32x4*>(out + (size_t)b * p.ldc + a) = v;
         }
+        __builtin_amdgcn_raw_buffer_store_b128(v, ro, o_out + it * 4 * p.ldc * 2, 0, 0);
       }
       if (EPI == EPI_DGELU && p.C2 != nullptr) {      // 4 row groups (lane >> 4) hold partial sums of the same 8 columns
         float* colsum = reinterpret_cast<float*>(p.C2);
-        const int a = a_base + rc * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float t = cs[e];
           t += __shfl_xor(t, 16, 64);
           t += __shfl_xor(t, 32, 64);
-          if (rrow == 0 && a < p.NA) unsafeAtomicAdd(colsum + a + e, t);
+          if (rrow == 0 && a_ok) unsafeAtomicAdd(colsum + a + e, t);
         }
       }
       __builtin_amdgcn_wave_barrier();
     }
   } else {
-    // fp32 image [64 b][64 a], two halves of the wave's 128 columns
+    // fp32 image [64 b][64 a], two halves of the wave's 128 columns.  EPI_RESID: the residual row segments of a half (and
+    // the per-row stochastic-depth scales) are requested before that half is transposed, half 1 while half 0 is stored.
+    const __amdgpu_buffer_rsrc_t ro = epi_rsrc(p.C, b_base, p.NB, p.ldc, 4);
+    const __amdgpu_buffer_rsrc_t rx = epi_rsrc(EPI == EPI_RESID ? p.aux : p.C, b_base, p.NB, EPI == EPI_RESID ? p.ldaux : p.ldc, 4);
+    u32x4 resv[2][16];
+    float rsc[16];
+    auto load_res = [&](int half) {
+      const int a = a_base + half * 64 + rc * 4;
+      const unsigned o_aux = a < p.NA ? (unsigned)(rrow * p.ldaux + a) * 4u : EPI_OOB;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) resv[half][it] = __builtin_amdgcn_raw_buffer_load_b128(rx, o_aux + it * 4 * p.ldaux * 4, 0, 0);
+    };
+    // the bias is added on the read side, where a lane keeps the same 4 columns for all 16 row segments of a half: two
+    // loads per lane, issued ahead of the residual requests (vmcnt retires in order)
+    f32x4 bias4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (p.bias != nullptr) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+        bias4[half] = *reinterpret_cast<const f32x4*>(p.bias + min(a_base + half * 64 + rc * 4, p.NA - 4));
+    }
+    if (EPI == EPI_RESID) {
+      load_res(0);
+#pragma unroll
+      for (int it = 0; it < 16; ++it) rsc[it] = 1.0f;
+      if (p.rowscale) {
+        // sample index of the wave's rows without a per-row division: one scalar quotient for the first row, then a
+        // compare per row when a sample spans >= 64 rows (always, for token sequences; the division is the general case)
+        const int rps = p.rows_per_scale;
+        const int q0 = __builtin_amdgcn_readfirstlane(b_base / rps), rem0 = b_base - q0 * rps;
+        const int qmax = __builtin_amdgcn_readfirstlane((p.NB - 1) / rps);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int x = rem0 + it * 4 + rrow;
+          const int q = rps >= 64 ? q0 + (x >= rps ? 1 : 0) : q0 + x / rps;
+          rsc[it] = p.rowscale[min(q, qmax)];
+        }
+      }
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -392,33 +451,24 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
         const int i = half * 2 + i2;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int a = a_base + i * 32 + 8 * g + 4 * h;
-          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-          if (p.bias != nullptr && a < p.NA) bv = *reinterpret_cast<const f32x4*>(p.bias + a);
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            f32x4 w = {acc[i][j][4 * g] + bv[0], acc[i][j][4 * g + 1] + bv[1], acc[i][j][4 * g + 2] + bv[2],
-                       acc[i][j][4 * g + 3] + bv[3]};
+            f32x4 w = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
             const int row = j * 32 + r;
             *reinterpret_cast<f32x4*>(wl + epi_off(row, i2 * 8 + 2 * g + h)) = w;
           }
         }
       }
       __builtin_amdgcn_wave_barrier();
+      if (EPI == EPI_RESID && half == 0) load_res(1);
+      const int a = a_base + half * 64 + rc * 4;
+      const unsigned o_out = a < p.NA ? (unsigned)(rrow * p.ldc + a) * 4u : EPI_OOB;
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
         const int row = it * 4 + rrow;
-        f32x4 v = *reinterpret_cast<const f32x4*>(wl + epi_off(row, rc));
-        const int b = b_base + row, a = a_base + half * 64 + rc * 4;
-        if (b < p.NB && a < p.NA) {
-          if (EPI == EPI_F32) {
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)b * p.ldc + a) = v;
-          } else if (EPI == EPI_RESID) {
-            const f32x4 rv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.aux) + (size_t)b * p.ldaux + a);
-            if (p.rowscale) v = v * p.rowscale[b / p.rows_per_scale];
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)b * p.ldc + a) = v + rv;
-          }
-        }
+        f32x4 v = *reinterpret_cast<const f32x4*>(wl + epi_off(row, rc)) + bias4[half];
+        if (EPI == EPI_RESID) v = v * rsc[it] + __builtin_bit_cast(f32x4, resv[half][it]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, o_out + it * 4 * p.ldc * 4, 0, 0);
       }
       __builtin_amdgcn_wave_barrier();
     }

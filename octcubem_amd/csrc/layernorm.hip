@@ -102,7 +102,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   }
   // Software-pipelined over rows: the loads of the NEXT row are issued before the current row is reduced, so every
   // wave keeps two rows (12-20 KB) in flight -- with one row per wave the kernel sat at ~35 % of HBM bandwidth.
-  f32x4 xn[NC];
+  // The incoming residual-stream gradient is part of the prefetch: vmcnt retires in order, so a load issued after the
+  // next row's requests and needed now would drain them all and leave one row in flight.
+  f32x4 xn[NC], rn[NC];
   u32x2 dn[NC];
   float mu_n = 0.f, rs_n = 0.f;
   auto issue = [&](int row) {
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       if (ci < nchunk) {
         xn[c] = *reinterpret_cast<const f32x4*>(x + (size_t)row * D + 4 * ci);
         dn[c] = *reinterpret_cast<const u32x2*>(dy + (size_t)row * D + 4 * ci);
+        if (dres != nullptr) rn[c] = *reinterpret_cast<const f32x4*>(dres + (size_t)row * D + 4 * ci);
       }
     }
   };
@@ -123,15 +126,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     f32x4 xh[NC], rv[NC];
     u32x2 dw[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) { xh[c] = xn[c]; dw[c] = dn[c]; }
+    for (int c = 0; c < NC; ++c) { xh[c] = xn[c]; dw[c] = dn[c]; rv[c] = rn[c]; }
     if (row + nwaves < M) issue(row + nwaves);
-    if (dres != nullptr) {
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const int ci = lane + 64 * c;
-        if (ci < nchunk) rv[c] = *reinterpret_cast<const f32x4*>(dres + (size_t)row * D + 4 * ci);
-      }
-    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -199,22 +195,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
-// out_k[c] += sum_b partial[b][k][c] for k = 0 (dgamma), 1 (dbeta), 2 (dxsum); 64 columns x 4 block-groups per workgroup
-__global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* __restrict__ partial, int nblocks, int D,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            float* __restrict__ dxsum) {
-  __shared__ float red[4][64];
+// out_k[c] += sum_b partial[b][k][c] for k = 0 (dgamma), 1 (dbeta), 2 (dxsum); 64 columns x 16 block-groups per workgroup,
+// fixed summation order (the result does not depend on scheduling)
+__global__ __launch_bounds__(1024) void ln_bwd_finish_kernel(const float* __restrict__ partial, int nblocks, int D,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             float* __restrict__ dxsum) {
+  __shared__ float red[16][64];
   const int k = blockIdx.y;
   float* dst = (k == 0) ? dgamma : (k == 1) ? dbeta : dxsum;
   if (dst == nullptr) return;
   const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
-  float s = 0.f;
-  if (c < D)
-    for (int b = grp; b < nblocks; b += 4) s += partial[((size_t)b * 3 + k) * D + c];
-  red[grp][cl] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < D) {
+    const float* src = partial + (size_t)k * D + c;
+    const size_t stride = (size_t)3 * D;
+    int b = grp;
+    for (; b + 48 < nblocks; b += 64) {
+      s0 += src[(size_t)b * stride];
+      s1 += src[(size_t)(b + 16) * stride];
+      s2 += src[(size_t)(b + 32) * stride];
+      s3 += src[(size_t)(b + 48) * stride];
+    }
+    for (; b < nblocks; b += 16) s0 += src[(size_t)b * stride];
+  }
+  red[grp][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (grp == 0 && c < D) dst[c] += (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+  if (grp == 0 && c < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][cl];
+    dst[c] += t;
+  }
 }
 
 static inline int ln_grid(int M) {
@@ -272,7 +284,7 @@ extern "C" int octmae_layernorm_bwd(const void* dy_bf16, const float* x, const f
   }
   OCTMAE_LAUNCH_CHECK();
   if (dgamma != nullptr || dbeta != nullptr || dxsum != nullptr) {
-    hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((D + 63) / 64, 3), dim3(256), 0, st, partial_ws, blocks, D, dgamma, dbeta, dxsum);
+    hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((D + 63) / 64, 3), dim3(1024), 0, st, partial_ws, blocks, D, dgamma, dbeta, dxsum);
     OCTMAE_LAUNCH_CHECK();
   }
   return 0;
