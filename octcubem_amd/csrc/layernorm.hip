@@ -33,17 +33,27 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
       b[c] = *reinterpret_cast<const f32x4*>(beta + 4 * ci);
     }
   }
-  for (int row = wave; row < M; row += nwaves) {
+  // the next row of the wave is requested before the current one is reduced (as in the backward kernel)
+  f32x4 vn[NC];
+  auto issue = [&](int row) {
     const float* xr = x + (size_t)row * D;
-    f32x4 v[NC];
-    float s = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int ci = lane + 64 * c;
-      if (ci < nchunk) {
-        v[c] = *reinterpret_cast<const f32x4*>(xr + 4 * ci);
-        s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
-      }
+      if (ci < nchunk) vn[c] = *reinterpret_cast<const f32x4*>(xr + 4 * ci);
+    }
+  };
+  if (wave < M) issue(wave);
+  for (int row = wave; row < M; row += nwaves) {
+    f32x4 v[NC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) v[c] = vn[c];
+    if (row + nwaves < M) issue(row + nwaves);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int ci = lane + 64 * c;
+      if (ci < nchunk) s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
     }
     const float mu = wave_sum(s) * invD;
     float q = 0.f;
