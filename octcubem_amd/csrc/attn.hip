@@ -147,7 +147,9 @@ __device__ __forceinline__ void dma_wait_barrier() {
   static_assert(CNT >= 0 && CNT < 64, "vmcnt is 6 bits");
   // gfx9 s_waitcnt immediate: vmcnt = {[15:14],[3:0]}, expcnt [6:4] = 7 (no wait), lgkmcnt [11:8] = 0
   __builtin_amdgcn_s_waitcnt((CNT & 15) | ((CNT >> 4) << 14) | (7 << 4) | (0 << 8));
+#ifndef ATT_EXPERIMENT_NO_BARRIER
   __builtin_amdgcn_s_barrier();
+#endif
 }
 
 // accumulator registers 8s..8s+7 -> bf16 B-operand fragment of k-step s

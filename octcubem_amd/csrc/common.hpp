@@ -81,6 +81,42 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return fmaf(u, q, 0.5f);
 }
 
+// Two-at-a-time forms on v_pk_fma_f32 / v_pk_mul_f32.  A packed op costs the same 4 cycles as two scalar ones, but the GEMM
+// epilogue runs with one or two waves per SIMD, where the limit is the ISSUE rate (one VALU instruction per ~5 cycles from one
+// wave, ~2.6 from two: tools/ubench/valu_rate.hip) -- half the instructions is up to twice the elements per cycle.
+// Same coefficients and evaluation order per element as gelu_f / dgelu_f: results are bit-identical.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float c) { return f32x2{c, c}; }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 gelu_f2(f32x2 x) {
+  const f32x2 u = {__builtin_amdgcn_fmed3f(x[0], -4.5f, 4.5f), __builtin_amdgcn_fmed3f(x[1], -4.5f, 4.5f)};
+  const f32x2 t = u * u;
+  f32x2 p = splat2(-7.715688019e-10f);
+  p = pk_fma(p, t, splat2(7.192630176e-08f));
+  p = pk_fma(p, t, splat2(-2.879689972e-06f));
+  p = pk_fma(p, t, splat2(6.548595686e-05f));
+  p = pk_fma(p, t, splat2(-9.478268993e-04f));
+  p = pk_fma(p, t, splat2(9.327514321e-03f));
+  p = pk_fma(p, t, splat2(-6.568239007e-02f));
+  p = pk_fma(p, t, splat2(3.986432605e-01f));
+  return x * pk_fma(u, p, splat2(0.5f));
+}
+__device__ __forceinline__ f32x2 dgelu_f2(f32x2 x) {
+  const f32x2 u = {__builtin_amdgcn_fmed3f(x[0], -5.0f, 5.0f), __builtin_amdgcn_fmed3f(x[1], -5.0f, 5.0f)};
+  const f32x2 t = u * u;
+  f32x2 q = splat2(-8.945184002e-12f);
+  q = pk_fma(q, t, splat2(1.221804868e-09f));
+  q = pk_fma(q, t, splat2(-7.286091231e-08f));
+  q = pk_fma(q, t, splat2(2.499930865e-06f));
+  q = pk_fma(q, t, splat2(-5.482182127e-05f));
+  q = pk_fma(q, t, splat2(8.080908045e-04f));
+  q = pk_fma(q, t, splat2(-8.191250186e-03f));
+  q = pk_fma(q, t, splat2(5.702680522e-02f));
+  q = pk_fma(q, t, splat2(-2.631234724e-01f));
+  q = pk_fma(q, t, splat2(7.970332990e-01f));
+  return pk_fma(u, q, splat2(0.5f));
+}
+
 // ---- MFMA wrappers ---------------------------------------------------------------------------
 // D(32x32) += A(32x16) * B(16x32).  lane l: r = l & 31, h = l >> 5.
 //   A fragment element j = A[row r][k = 8h + j]      B fragment element j = B[k = 8h + j][col r]

@@ -49,7 +49,26 @@ struct GemmParams {
   int ktiles, ktiles_per_split;
   const float* rowscale;   // EPI_RESID only: C = aux + rowscale[b / rows_per_scale] * (X + bias)   (stochastic depth); NULL = 1
   int rows_per_scale;
+  int cgroup;              // 256-tile kernels: column tiles (a) per group of the tile order, see tile_coord()
 };
+
+// Tile order of the 256-tile kernels.  xcd_remap hands every XCD one contiguous range of t.  Inside a group of `cgroup`
+// column tiles the order is a-fastest (neighbouring workgroups share the activation row panel B), and a group is swept over
+// ALL row tiles before the next group starts.  With cgroup == tiles_a that is the plain a-fastest order: the 32 workgroups of
+// an XCD touch up to 16 weight panels at once, 8 MB for a [4096 x 1024] weight against a 4 MB L2, and every round of
+// workgroups fetches the whole weight matrix again (1.3 GB per fc1 forward, 8x the activations it reads).  With a group
+// whose weight panels fit the L2 (<= 2 MB) they are fetched once per XCD and stay; the row panels are then read once per
+// group instead of once.
+__device__ __forceinline__ void tile_coord(const GemmParams& p, int t, int& ta, int& tb) {
+  const int c = p.cgroup;
+  if (c >= p.tiles_a) {
+    tb = t / p.tiles_a; ta = t - tb * p.tiles_a;
+  } else {
+    const int per = c * p.tiles_b;           // cgroup divides tiles_a (host side)
+    const int cg = t / per, r = t - cg * per;
+    tb = r / c; ta = cg * c + (r - tb * c);
+  }
+}
 
 // ---- LDS images ------------------------------------------------------------------------------
 // k-contiguous tile: [128 rows][64 k] bf16, 128-B rows, 16-B chunk c of row r at r*128 + ((c ^ ((r>>1)&7))<<4)
@@ -354,21 +373,36 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
 #pragma unroll
       for (int it = 0; it < 16; ++it) prev[it] = __builtin_amdgcn_raw_buffer_load_b128(rx, o_aux + it * 4 * p.ldaux * 2, 0, 0);
     }
+    // All 16 bias quads of the lane are requested together before the first store.  vmcnt retires in order: a bias load
+    // issued after stores -- the second pass of EPI_GELU reloaded them -- waits for every store ahead of it to be
+    // acknowledged, and 16 separately guarded loads were 16 dependent L2 round trips per pass (most of the 8.9 k / 21.6 k
+    // cycles the plain / GELU epilogue took).
+    f32x4 bias_q[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bias_q[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (EPI != EPI_DGELU && p.bias != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          bias_q[i][g] = *reinterpret_cast<const f32x4*>(p.bias + min(a_base + i * 32 + 8 * g + 4 * h, p.NA - 4));
+    }
 #pragma unroll
     for (int pass = 0; pass < (EPI == EPI_GELU ? 2 : 1); ++pass) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int aw = a_base + i * 32 + 8 * g + 4 * h;
-          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-          if (EPI != EPI_DGELU && p.bias != nullptr && aw < p.NA) bv = *reinterpret_cast<const f32x4*>(p.bias + aw);
+          const f32x4 bv = bias_q[i][g];
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             u32x2 w = {pack2bf(acc[i][j][4 * g] + bv[0], acc[i][j][4 * g + 1] + bv[1]),
                        pack2bf(acc[i][j][4 * g + 2] + bv[2], acc[i][j][4 * g + 3] + bv[3])};
             if (pass == 1) {   // activation of the bf16-ROUNDED pre-activation (what backward differentiates)
-              w = u32x2{pack2bf(gelu_f(bflo(w[0])), gelu_f(bfhi(w[0]))), pack2bf(gelu_f(bflo(w[1])), gelu_f(bfhi(w[1])))};
+              const f32x2 y0 = gelu_f2(f32x2{bflo(w[0]), bfhi(w[0])}), y1 = gelu_f2(f32x2{bflo(w[1]), bfhi(w[1])});
+              w = u32x2{pack2bf(y0[0], y0[1]), pack2bf(y1[0], y1[1])};
             }
             const int row = j * 32 + r;
             *reinterpret_cast<u32x2*>(wl + epi_off(row, 4 * i + g) + 8 * h) = w;
@@ -385,7 +419,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
         if (EPI == EPI_DGELU) {
           const u32x4 pre = prev[it];   // zeros outside the matrix: gelu'(0) * v is stored nowhere and summed nowhere
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = pack2bf(bflo(v[e]) * dgelu_f(bflo(pre[e])), bfhi(v[e]) * dgelu_f(bfhi(pre[e])));
+          for (int e = 0; e < 4; ++e) {
+            const f32x2 y = f32x2{bflo(v[e]), bfhi(v[e])} * dgelu_f2(f32x2{bflo(pre[e]), bfhi(pre[e])});
+            v[e] = pack2bf(y[0], y[1]);
+          }
           if (p.C2 != nullptr && b_base + row < p.NB) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { cs[2 * e] += bflo(v[e]); cs[2 * e + 1] += bfhi(v[e]); }
@@ -484,7 +521,8 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const GemmParams p) {
 
   const int nt = p.tiles_a * p.tiles_b;
   const int t = xcd_remap(blockIdx.x, nt);
-  const int tb = t / p.tiles_a, ta = t - tb * p.tiles_a;
+  int ta, tb;
+  tile_coord(p, t, ta, tb);
   const int a0 = ta * T2, b0 = tb * T2;
 
   const int kt0 = blockIdx.z * p.ktiles_per_split;
@@ -591,7 +629,8 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const GemmParams p) {
 
   const int nt = p.tiles_a * p.tiles_b;
   const int t = xcd_remap(blockIdx.x, nt);
-  const int tb = t / p.tiles_a, ta = t - tb * p.tiles_a;
+  int ta, tb;
+  tile_coord(p, t, ta, tb);
   const int a0 = ta * T2, b0 = tb * T2;
 
   const int kt0 = blockIdx.z * p.ktiles_per_split;
@@ -810,6 +849,20 @@ static int gemm_impl(const void* A, const void* B, void* C, void* C2, const floa
   const int tile = big ? T2 : TA;
   p.tiles_a = (NA + tile - 1) / tile;
   p.tiles_b = (NB + tile - 1) / tile;
+  // column-tile group of the tile order (tile_coord): groups of 4 column tiles when there are >= 16 of them and 4 weight
+  // panels fit half the L2 (K <= 1024: the fc1 forward and the fc2 dgrad of ViT-L).  Measured same-box: fc1 forward
+  // 891 -> 871 us, fc2 dgrad+dgelu 801 -> 790 us; narrower groups (K >= 3072, one panel per group) lose 3-5 % to the
+  // activation re-reads and 12 column tiles (qkv) gain nothing, so those keep the plain order.
+  p.cgroup = p.tiles_a;
+  if (big && epilogue != EPI_ACCUM) {
+    static const int force = getenv("OCTMAE_CGROUP") ? atoi(getenv("OCTMAE_CGROUP")) : 0;
+    const size_t panel = (size_t)T2 * K * 2;
+    if (force > 0) {
+      if (p.tiles_a % force == 0) p.cgroup = force;
+    } else if (p.tiles_a >= 16 && p.tiles_a % 4 == 0 && 4 * panel <= (2u << 20)) {
+      p.cgroup = 4;
+    }
+  }
   if (splitk > p.ktiles) splitk = p.ktiles;
   p.ktiles_per_split = (p.ktiles + splitk - 1) / splitk;
   splitk = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
