@@ -353,7 +353,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* base, int
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
                                            __builtin_amdgcn_readfirstlane(rows * ld * esize), 0x00020000);
 }
-constexpr unsigned EPI_OOB = 0x7ffffff0u;   // byte offset past any num_records above: masks a lane whose columns are >= NA
+constexpr unsigned EPI_OOB = 0x7ffffff0u;
+#ifndef EPI_STORE_AUX
+#define EPI_STORE_AUX 3   // sc0 nt: streaming stores (outputs are >= 100 MB and not re-read before they leave the L2); measured -5..6 % on the bf16 / GELU forwards
+#endif   // byte offset past any num_records above: masks a lane whose columns are >= NA
 
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&acc)[4][2], int a_base, int b_base, int lane,
@@ -428,7 +431,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
             for (int e = 0; e < 4; ++e) { cs[2 * e] += bflo(v[e]); cs[2 * e + 1] += bfhi(v[e]); }
           }
         }
-        __builtin_amdgcn_raw_buffer_store_b128(v, ro, o_out + it * 4 * p.ldc * 2, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, ro, o_out + it * 4 * p.ldc * 2, 0, EPI_STORE_AUX);
       }
       if (EPI == EPI_DGELU && p.C2 != nullptr) {      // 4 row groups (lane >> 4) hold partial sums of the same 8 columns
         float* colsum = reinterpret_cast<float*>(p.C2);
@@ -505,7 +508,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
         const int row = it * 4 + rrow;
         f32x4 v = *reinterpret_cast<const f32x4*>(wl + epi_off(row, rc)) + bias4[half];
         if (EPI == EPI_RESID) v = v * rsc[it] + __builtin_bit_cast(f32x4, resv[half][it]);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, o_out + it * 4 * p.ldc * 4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, o_out + it * 4 * p.ldc * 4, 0, EPI_STORE_AUX);
       }
       __builtin_amdgcn_wave_barrier();
     }
