@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = fmaf((v[c][e] - mu) * rs, g[c][e], b[c][e]);
         u32x2 w = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
-        *reinterpret_cast<u32x2*>(yr + 4 * ci) = w;
+        __builtin_nontemporal_store(w, reinterpret_cast<u32x2*>(yr + 4 * ci));
       }
     }
   }
@@ -169,10 +169,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] += rv[c][e];
         }
-        *reinterpret_cast<f32x4*>(dx + (size_t)row * D + 4 * ci) = o;
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dx + (size_t)row * D + 4 * ci));
         if (dxb != nullptr) {
           u32x2 wv = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
-          *reinterpret_cast<u32x2*>(dxb + (size_t)row * D + 4 * ci) = wv;
+          __builtin_nontemporal_store(wv, reinterpret_cast<u32x2*>(dxb + (size_t)row * D + 4 * ci));
         }
         if (want_dxsum) {
 #pragma unroll
