@@ -515,9 +515,26 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
   }
 }
 
+// Optional per-workgroup timeline (make -C octcubem_amd/csrc trace; tools/gemm_trace.py): 100 MHz wall-clock stamps at
+// workgroup start, k-loop start, k-loop end and workgroup end, plus the hardware id, for the two-stage kernel.
+#ifdef GEMM_TRACE
+__device__ unsigned long long* g_trace = nullptr;   // [workgroup][6]
+#define TRACE_MARK(slot) do { if (g_trace && threadIdx.x == 0) g_trace[(size_t)blockIdx.x * 6 + (slot)] = wall_clock64(); } while (0)
+#else
+#define TRACE_MARK(slot) do {} while (0)
+#endif
 template <bool A_KS, bool B_KS, int EPI, bool OUT_AB>
 __global__ __launch_bounds__(512, 1) void gemm256_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // A0 A1 B0 B1
+  TRACE_MARK(0);
+#ifdef GEMM_TRACE
+  if (g_trace && threadIdx.x == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_trace[(size_t)blockIdx.x * 6 + 4] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wid >> 2, wb = wid & 3;
@@ -550,6 +567,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const GemmParams p) {
     dma_tile<A_KS>(ra, smem, wid, lane, a0, kt0 * TK, p.lda);
     dma_tile<B_KS>(rb, smem + 2 * TILE2_BYTES, wid, lane, b0, kt0 * TK, p.ldb);
     __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+    TRACE_MARK(1);
     for (int it = 0; it < nk; ++it) {
       if (it + 1 < nk) {
         dma_tile<A_KS>(ra, smem + ((it + 1) & 1) * TILE2_BYTES, wid, lane, a0, (kt0 + it + 1) * TK, p.lda);
@@ -572,12 +590,20 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const GemmParams p) {
       __syncthreads();
     }
   }
+  TRACE_MARK(2);
   if (OUT_AB || (p.NA & 7) != 0) {
     gemm_epilogue<EPI, OUT_AB, 4, 2>(p, acc, a0 + wa * 128, b0 + wb * 64, lane, gridDim.z > 1);
   } else {
     gemm_epilogue_lds<EPI>(p, acc, a0 + wa * 128, b0 + wb * 64, lane, smem + wid * 16384);
   }
+  TRACE_MARK(3);
 }
+#ifdef GEMM_TRACE
+extern "C" int octmae_debug_set_gemm_trace(void* ptr) {   // trace builds only; not part of include/octmae.h
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(ptr);
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &q, sizeof(q));
+}
+#endif
 
 // =====================================================================================================
 // Phased main loop for the same 256 x 256 x 64 tile (cdna_hip_programming.md section 5, "8-phase" structure, re-derived for
