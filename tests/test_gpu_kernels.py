@@ -120,6 +120,53 @@ def test_gemm_forward_epilogues(M, N, K, tile_variant):
     assert float((act.double() - ref_act).abs().max()) < 2e-2 * float(ref_act.abs().max())
 
 
+@pytest.mark.parametrize("M,N,K", [(1281, 384, 128), (600, 512, 256), (2562, 768, 512), (333, 264, 64)])
+def test_gemm_epilogues_stay_inside_the_output(M, N, K, tile_variant):
+    """Every epilogue writes through an output whose rows are wider than the matrix (ldc > N) and which sits between two guard
+    rows: the clipped stores (buffer descriptors in the 256-tile kernel, branches in the 128-tile one) must leave the guard
+    rows and the padding columns untouched, and the residual / pre-activation reads must honour their own leading dimension."""
+    g = torch.Generator().manual_seed(M + N)
+    x = bf(torch.randn(M, K, generator=g)).to(DEV)
+    w = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    ld = N + 24
+    ref = x.double() @ w.double().t() + b.double()
+
+    def guarded(dtype):
+        big = torch.full((M + 2, ld), 7.0, dtype=dtype, device=DEV)
+        return big, big[1:]
+
+    def check(big, exp, tol):
+        assert rel(big[1:M + 1, :N], exp) < tol
+        assert bool((big[0] == 7).all()) and bool((big[M + 1] == 7).all()) and bool((big[1:M + 1, N:] == 7).all())
+
+    big, c = guarded(BF16)
+    ops._gemm(w, x, c, N, M, K, K, K, ld, 0, 0, ops.EPI_BF16, bias=b)
+    check(big, ref, 3e-3)
+    big, c = guarded(torch.float32)
+    ops._gemm(w, x, c, N, M, K, K, K, ld, 0, 0, ops.EPI_F32, bias=b)
+    check(big, ref, 2e-6)
+    resbig = torch.randn(M, N + 8, generator=g).to(DEV)
+    big, c = guarded(torch.float32)
+    ops._gemm(w, x, c, N, M, K, K, K, ld, 0, 0, ops.EPI_RESID, bias=b, aux=resbig, ldaux=N + 8)
+    check(big, ref + resbig[:, :N].double(), 2e-6)
+    big, c = guarded(BF16)
+    big2, c2 = guarded(BF16)
+    ops._gemm(w, x, c, N, M, K, K, K, ld, 0, 0, ops.EPI_GELU, C2=c2, bias=b)
+    check(big, ref, 3e-3)
+    check(big2, torch.nn.functional.gelu(big[1:M + 1, :N].double()), 3e-3)
+    # dgrad with GELU' : out [M, K] = (dy @ w) * gelu'(pre), pre read with its own leading dimension
+    dy = bf(torch.randn(M, N, generator=g)).to(DEV)
+    pre = bf(torch.randn(M, K + 16, generator=g)).to(DEV)
+    ldk = K + 24
+    bigk = torch.full((M + 2, ldk), 7.0, dtype=BF16, device=DEV)
+    ops._gemm(w, dy, bigk[1:], K, M, N, K, N, ldk, 1, 0, ops.EPI_DGELU, aux=pre, ldaux=K + 16)
+    xg = pre[:, :K].double().requires_grad_(True)
+    torch.nn.functional.gelu(xg).backward(dy.double() @ w.double())
+    assert rel(bigk[1:M + 1, :K], xg.grad) < 3e-3
+    assert bool((bigk[0] == 7).all()) and bool((bigk[M + 1] == 7).all()) and bool((bigk[1:M + 1, K:] == 7).all())
+
+
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_dgrad_and_wgrad(M, N, K, tile_variant):
     g = torch.Generator().manual_seed(M + N * 3)
