@@ -337,6 +337,18 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : ATT_OCC_FWD64)) vo
     dma_wait_barrier<DMA_CNT>();
   };
 
+  // A wave whose 32 queries all lie past N (the last workgroup of a sequence of 128 k + 1 tokens keeps one live wave of four)
+  // only stages tiles and keeps the barriers, in a loop of its own: the SIMD time it would have spent on masked work goes to
+  // the other workgroups resident on the CU.
+  if (__builtin_amdgcn_readfirstlane(q0) >= N) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < ntiles; ++t) {
+      issue(t + NB, t + NB - 1);
+      dma_wait_barrier<DMA_CNT>();
+    }
+    return;
+  }
   f32x16 sA[2], sB[2];
   qk(Kbuf, sA);
   // S_0 is the only score tile computed outside a step: step 0 restages slot 0 of the K ring (K_NB) right away, so every
@@ -518,6 +530,13 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DQ32 : 2)) void attn_bwd_d
       }
     }
   };
+  if (__builtin_amdgcn_readfirstlane(bc.x * 128 + wid * 32) >= N) {   // no live query in this wave: stage and synchronise only
+    for (int t = 0; t + 1 < ntiles; ++t) {
+      issue(t + NB - 1);
+      dma_wait_barrier<DMA_CNT>();
+    }
+    return;
+  }
   for (int t = 0; t + 1 < ntiles; ++t) {
     issue(t + NB - 1);
     tile(t, std::false_type{});
@@ -613,6 +632,13 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DKV32 : 2)) void attn_bwd_
   for (int s = 1 - NB; s < 0; ++s) issue(s + NB - 1);
   dma_wait_barrier<DMA_CNT>();
 
+  if (__builtin_amdgcn_readfirstlane(bc.x * 128 + wid * 32) >= N) {   // no live key in this wave: stage and synchronise only
+    for (int t = 0; t < ntiles; ++t) {
+      issue(t + NB - 1);
+      dma_wait_barrier<DMA_CNT>();
+    }
+    return;
+  }
   for (int t = 0; t < ntiles; ++t) {
     issue(t + NB - 1);
     const char* cQ = (smem + (t % NB) * T::BYTES);

@@ -12,7 +12,10 @@ def t(f, iters=10):
     for _ in range(iters): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / iters
-for name, N, H, HD in (("enc", 1281, 16, 64), ("dec", 5121, 16, 32)):
+SHAPES = (("enc", 1281, 16, 64), ("dec", 5121, 16, 32))
+if len(sys.argv) > 2:      # extra shapes: N:H:HD ...
+    SHAPES = tuple((f"n{a.split(':')[0]}", *(int(v) for v in a.split(":"))) for a in sys.argv[2:])
+for name, N, H, HD in SHAPES:
     qkv = torch.randn(B * N, 3 * H * HD, device="cuda").to(torch.bfloat16); do = torch.randn(B * N, H * HD, device="cuda").to(torch.bfloat16)
     o, lse = ops.attn_fwd(qkv, B, N, H, HD, HD ** -0.5)
     rowc = torch.empty(2 * B * H * N, dtype=torch.float32, device="cuda"); dqkv = torch.empty_like(qkv)
