@@ -6,8 +6,9 @@
         bench.py --gpus N --steps K --warmup W                       # N > 1: one rank per GPU over RCCL
 
 A "step" is one optimizer step over the fixed GLOBAL batch (default 256 volumes, BASELINE config 3): every rank runs
-global_batch / N volumes as micro-batches (default min(64, global_batch / N)) with gradient accumulation, the flat-arena all-reduce overlaps the
-last micro-batch's backward, then grad-norm + fused AdamW.  Strong scaling: total work per step is fixed.
+global_batch / N volumes as micro-batches with gradient accumulation (default: 128 volumes on a single GPU -- 246 of its
+268 GiB, with a fall-back to 64 should the warm-up run out of memory -- and min(64, global_batch / N) on N > 1), the
+flat-arena all-reduce overlaps the last micro-batch's backward, then grad-norm + fused AdamW.  Strong scaling: total work per step is fixed.
 Inputs are synthetic fp32 volumes already resident in HBM; weights are the reference's random init; masking noise comes
 from the device RNG inside the timed region.  Rank 0 prints ONE JSON line.
 
@@ -66,19 +67,18 @@ def pmc_traffic(kind, micro_batch):
     profiles/README.md): (2 x FETCH_SIZE + WRITE_SIZE) x 1024, FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM.  The
     profiler cannot wrap the process it runs in, so this is the offline measurement of the same per-launch shapes; None when
     the file was taken at another micro-batch (other shapes)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    if not os.path.exists(path):
-        return None
-    try:
-        t = json.load(open(path))
-        if int(t.get("_meta", {}).get("micro_batch", 32)) != micro_batch:
-            return None
-        for name in _PMC_KERNEL[kind]:
-            if name in t:
-                return t[name]["hbm_bytes_per_launch_corrected"]
-        return None
-    except Exception:
-        return None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic*.json")), reverse=True):
+        try:
+            t = json.load(open(path))
+            if int(t.get("_meta", {}).get("micro_batch", 32)) != micro_batch:
+                continue
+            for name in _PMC_KERNEL[kind]:
+                if name in t:
+                    return t[name]["hbm_bytes_per_launch_corrected"]
+        except Exception:
+            continue
+    return None
 
 
 def main():
@@ -87,7 +87,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--global-batch", type=int, default=256)
-    ap.add_argument("--micro-batch", type=int, default=64)
+    ap.add_argument("--micro-batch", type=int, default=0,
+                    help="volumes per forward/backward; 0 = auto: 128 on a single GPU when it fits (falls back to 64 on an "
+                         "out-of-memory error during warm-up), min(64, global_batch / N) otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--clip-grad", type=float, default=None)
@@ -115,9 +117,14 @@ def main():
 
     assert args.global_batch % world == 0
     per_rank = args.global_batch // world
-    mb = min(args.micro_batch, per_rank)
-    assert per_rank % mb == 0
-    accum = per_rank // mb
+    if args.micro_batch > 0:
+        candidates = [min(args.micro_batch, per_rank)]
+    elif world == 1 and per_rank % 128 == 0 and torch.cuda.mem_get_info(dev)[1] >= 280e9:
+        # ~1.9 GiB of saved activations per volume: 128 volumes take 246 of the 268 GiB; +1.6 % over 64 (longer k-loops in the
+        # weight-gradient GEMMs, fewer tile-round tails).  Only without peers: a rank that fell back alone would hang the others.
+        candidates = [128, 64]
+    else:
+        candidates = [min(64, per_rank)]
 
     torch.manual_seed(0)                                   # identical initial weights on every rank
     model = models_mae.octcube_vit_large_3dmae().to(dev)
@@ -130,26 +137,43 @@ def main():
     scaler = misc.NativeScalerWithGradNormCount(fp32=True, reducer=reducer)
     params = list(model.parameters())
 
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)   # rank r sees different volumes (seed + rank, main_pretrain…:306)
-    pool = [torch.rand(mb, 1, 60, 256, 256, device=dev, generator=g) for _ in range(min(accum, 2))]
-
-    def step():
-        opt.zero_grad()
-        last = None
-        for i in range(accum):
-            loss, _, _ = model(pool[i % len(pool)], mask_ratio=0.75)
-            last = loss
-            scaler(loss / accum, opt, parameters=params, update_grad=(i == accum - 1), clip_grad=args.clip_grad)
-        return last
-
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
+    for ci, mb in enumerate(candidates):
+        assert per_rank % mb == 0
+        accum = per_rank // mb
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)   # rank r sees different volumes (seed + rank, main_pretrain…:306)
+        pool = None
+        try:
+            pool = [torch.rand(mb, 1, 60, 256, 256, device=dev, generator=g) for _ in range(min(accum, 2))]
+
+            def step():
+                opt.zero_grad()
+                last = None
+                for i in range(accum):
+                    if os.environ.get("OCTMAE_BENCH_FAKE_OOM") and mb == 128:     # exercises the fallback (tests only)
+                        raise torch.OutOfMemoryError("simulated")
+                    loss, _, _ = model(pool[i % len(pool)], mask_ratio=0.75)
+                    last = loss
+                    scaler(loss / accum, opt, parameters=params, update_grad=(i == accum - 1), clip_grad=args.clip_grad)
+                return last
+
+            for _ in range(max(args.warmup, 1) if len(candidates) > 1 and ci == 0 else args.warmup):
+                step()
+            fence()
+            break
+        except torch.OutOfMemoryError:
+            if ci + 1 == len(candidates):
+                raise
+            pool = None
+            torch.cuda.synchronize()
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            print(f"[bench] micro-batch {mb} does not fit, falling back to {candidates[ci + 1]}", file=sys.stderr, flush=True)
     if not args.no_kernel_timing:
         ops.KTIMER = ops.KernelTimer()
     t0 = time.perf_counter()
