@@ -540,12 +540,22 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const GemmParams p) {
   const int wa = wid >> 2, wb = wid & 3;
 
   const int nt = p.tiles_a * p.tiles_b;
-  const int t = xcd_remap(blockIdx.x, nt);
+  // Split-K launches (weight gradients) are ordered k-slice-major over the XCD-contiguous logical index: the ~32 workgroups
+  // an XCD runs at a time then belong to ONE k slice and to neighbouring tiles, so the operand panels they stream are
+  // shared through that XCD's L2 (with the slice index on blockIdx.z taken as is, every XCD held 8 tiles of EACH slice and
+  // fetched 36 panel streams per 32 workgroups instead of 12-18; the kernel ran at the HBM ceiling, 6 TB/s).
+  int t, kz;
+  if (gridDim.z > 1) {
+    const int L = xcd_remap((int)(blockIdx.x + nt * blockIdx.z), nt * (int)gridDim.z);
+    kz = L / nt; t = L - kz * nt;
+  } else {
+    t = xcd_remap(blockIdx.x, nt); kz = 0;
+  }
   int ta, tb;
   tile_coord(p, t, ta, tb);
   const int a0 = ta * T2, b0 = tb * T2;
 
-  const int kt0 = blockIdx.z * p.ktiles_per_split;
+  const int kt0 = kz * p.ktiles_per_split;
   int kt1 = kt0 + p.ktiles_per_split;
   if (kt1 > p.ktiles) kt1 = p.ktiles;
   const int nk = kt1 - kt0;
@@ -657,12 +667,22 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const GemmParams p) {
   const int wa = wid >> 2, wb = wid & 3;          // wa = 1: the late group (waves 4-7)
 
   const int nt = p.tiles_a * p.tiles_b;
-  const int t = xcd_remap(blockIdx.x, nt);
+  // Split-K launches (weight gradients) are ordered k-slice-major over the XCD-contiguous logical index: the ~32 workgroups
+  // an XCD runs at a time then belong to ONE k slice and to neighbouring tiles, so the operand panels they stream are
+  // shared through that XCD's L2 (with the slice index on blockIdx.z taken as is, every XCD held 8 tiles of EACH slice and
+  // fetched 36 panel streams per 32 workgroups instead of 12-18; the kernel ran at the HBM ceiling, 6 TB/s).
+  int t, kz;
+  if (gridDim.z > 1) {
+    const int L = xcd_remap((int)(blockIdx.x + nt * blockIdx.z), nt * (int)gridDim.z);
+    kz = L / nt; t = L - kz * nt;
+  } else {
+    t = xcd_remap(blockIdx.x, nt); kz = 0;
+  }
   int ta, tb;
   tile_coord(p, t, ta, tb);
   const int a0 = ta * T2, b0 = tb * T2;
 
-  const int kt0 = blockIdx.z * p.ktiles_per_split;
+  const int kt0 = kz * p.ktiles_per_split;
   int kt1 = kt0 + p.ktiles_per_split;
   if (kt1 > p.ktiles) kt1 = p.ktiles;
   const int nk = kt1 - kt0;
@@ -891,6 +911,13 @@ static int gemm_impl(const void* A, const void* B, void* C, void* C2, const floa
     } else if (p.tiles_a >= 16 && p.tiles_a % 4 == 0 && 4 * panel <= (2u << 20)) {
       p.cgroup = 4;
     }
+  } else if (big && p.tiles_a * p.tiles_b > 32) {
+    // weight gradients: the ~32 workgroups an XCD runs at a time should form a compact rectangle of tiles (8 x 4 rather than
+    // 16 x 2 for fc1's 16 x 4 tiles): c column tiles x all row tiles, c = 32 / tiles_b rounded down to a divisor of tiles_a
+    int c = 32 / p.tiles_b;
+    if (c < 1) c = 1;
+    while (c > 1 && p.tiles_a % c != 0) --c;
+    p.cgroup = c;
   }
   if (splitk > p.ktiles) splitk = p.ktiles;
   p.ktiles_per_split = (p.ktiles + splitk - 1) / splitk;
