@@ -170,8 +170,8 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // So the per-score work is cut to  exp + cvt (+ max):
 //   * Q (forward, dQ) / K (dK/dV) fragments are pre-multiplied by scale*log2(e) once per workgroup and the S accumulator
 //     starts at the row constant (-running max, or -LSE*log2e in backward): the MFMA result IS the exp2 argument;
-//   * head_dim 32 (where the MFMA pipe has slack) gets its softmax row sums from one extra MFMA against an all-ones
-//     operand instead of 32 v_add per tile;
+//   * (the softmax row sums can come from one extra MFMA against an all-ones operand instead of 32 v_add per tile --
+//     ONES_SUM in the forward; off since the kernel time became ~ MFMA + VALU cycles, see there);
 //   * the running max moves only when a row exceeds it by more than RESCALE_SLACK (log2 units), P <= 2^8.
 constexpr float RESCALE_SLACK = 8.0f;
 
@@ -214,7 +214,11 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : ATT_OCC_FWD64)) vo
   const int q0 = bc.x * 128 + wid * 32;
   const int qrow = q0 + r;
 
-  constexpr bool ONES_SUM = (HD == 32);
+  // Row sums on the VALU (4 add chains per lane).  An all-ones MFMA operand can produce them instead (kept below, off): that
+  // was the better trade while the softmax was the clear limiter, but with the optimistic forward and pre-scaled Q the kernel
+  // time is ~ MFMA + VALU cycles, and 4 extra MFMAs per 64-key step (128 cycles) cost more than 32 v_add (64 cycles):
+  // 2 306 -> 2 219 us on the decoder shape (32 x 16 x 5121 x 32), same box.
+  constexpr bool ONES_SUM = false;
   const float sc2 = scale * LOG2E;
   bf16x8 qf[KS];   // Q^T fragments, pre-scaled by scale*log2(e): S accumulates directly in the exp2 domain
 #pragma unroll
