@@ -196,6 +196,25 @@ def test_gemm_dgrad_and_wgrad(M, N, K, tile_variant):
     assert rel(gw2, gw_ref) < 1e-5
 
 
+@pytest.mark.parametrize("N,K,M", [(4096, 1024, 1500), (2048, 1280, 900), (1536, 2304, 700), (3072, 1024, 2000)])
+def test_wgrad_large_weight_tile_orders(N, K, M, tile_variant):
+    """Weight gradients whose [N x K] output has more than 32 tiles of 256 x 256 take the k-slice-major, column-grouped
+    workgroup order (tile_coord with cgroup < tiles_a, split-K over the rows): every tile of every slice must be produced
+    exactly once -- checked against an fp64 product, on top of a non-zero accumulator."""
+    g = torch.Generator().manual_seed(N + K + M)
+    x = bf(torch.randn(M, K, generator=g)).to(DEV)
+    dy = bf(torch.randn(M, N, generator=g)).to(DEV)
+    gw0 = torch.randn(N, K, generator=g).to(DEV)
+    ref = gw0.double() + dy.double().t() @ x.double()
+    gw = gw0.clone()
+    ops.linear_wgrad_accum(dy, x, gw)
+    assert rel(gw, ref) < 1e-5
+    for splitk in (1, 3, 7):
+        gw = gw0.clone()
+        ops._gemm(dy, x, gw, N, K, M, N, K, K, 1, 1, ops.EPI_ACCUM, splitk=splitk)
+        assert rel(gw, ref) < 1e-5
+
+
 def test_gemm_rejects_bad_arguments():
     x = torch.zeros(8, 12, dtype=BF16, device=DEV)      # K = 12 not a multiple of 8
     w = torch.zeros(8, 12, dtype=BF16, device=DEV)
