@@ -73,7 +73,8 @@ def test_probe_ds_read_tr_lane_map():
 
 # ------------------------------------------------------------------------------------------------ GEMM
 GEMM_SHAPES = [(128, 128, 64), (256, 384, 128), (200, 136, 72), (1281, 384, 128), (64, 64, 64), (5121, 192, 64), (130, 768, 512),
-               (600, 512, 256), (2000, 1024, 1024), (3000, 512, 256), (2562, 768, 512)]
+               (600, 512, 256), (2000, 1024, 1024), (3000, 512, 256), (2562, 768, 512),
+               (600, 4096, 256), (700, 512, 4096)]      # 16 column tiles, K <= 1024: the column-grouped tile order (forward / dgrad)
 
 
 @pytest.fixture(params=["auto", "tile128", "twostage", "phased"])
