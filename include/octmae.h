@@ -70,8 +70,12 @@ int octmae_layernorm_bwd_ws_floats(int M, int D);
 int octmae_attn_fwd(const void* qkv, void* o, float* lse, int* flag_ws, int B, int N, int H, int HD, float scale, void* stream);
 int octmae_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* rowc_ws, void* dqkv, int B,
                     int N, int H, int HD, float scale, void* stream);
-/* the three launches octmae_attn_bwd is made of, callable one by one.  rowconst fills rowc [2][B][H][N] with the per-query
- * constants the two gradient kernels start their accumulators from: rowc[0] = -lse * log2(e), rowc[1] = -rowsum(dO * O). */
+/* octmae_attn_bwd = octmae_attn_bwd_dq_rowconst + octmae_attn_bwd_dkv: the dQ kernel computes the per-query constants the
+ * gradient kernels start their accumulators from, rowc[0] = -lse * log2(e), rowc[1] = -rowsum(dO * O), for its own query rows
+ * and WRITES them to rowc [2][B][H][N] for the dK/dV kernel.  The separate pre-pass (rowconst) followed by octmae_attn_bwd_dq,
+ * which only reads rowc, is the same computation in three launches. */
+int octmae_attn_bwd_dq_rowconst(const void* qkv, const void* o, const void* dout, const float* lse, float* rowc, void* dqkv, int B,
+                                int N, int H, int HD, float scale, void* stream);
 int octmae_attn_bwd_rowconst(const void* o, const void* dout, const float* lse, float* rowc, int B, int N, int H, int HD,
                              void* stream);
 int octmae_attn_bwd_dq(const void* qkv, const void* dout, const float* rowc, void* dqkv, int B, int N, int H, int HD, float scale,

@@ -23,6 +23,7 @@ SIGNATURES = {
     "octmae_attn_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "octmae_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "octmae_attn_bwd_rowconst": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "octmae_attn_bwd_dq_rowconst": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "octmae_attn_bwd_dq": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "octmae_attn_bwd_dkv": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "octmae_random_masking_ids": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

@@ -443,8 +443,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // =====================================================================================================
 template <int HD>
 __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DQ32 : 2)) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                             const float* __restrict__ rowc, bf16_t* __restrict__ dqkv, int N,
-                                                             int H, float scale) {
+                                                             float* __restrict__ rowc, bf16_t* __restrict__ dqkv, int N,
+                                                             int H, float scale, const bf16_t* __restrict__ o_in,
+                                                             const float* __restrict__ lse_in) {
   constexpr int KS = HD / 16, DB = HD / 32;
   using T = Tile<HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -463,20 +464,37 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_DQ32 : 2)) void attn_bwd_d
   const float sc2 = scale * LOG2E;
 
   bf16x8 qf[KS], dof[KS];
+  float dpart = 0.f;                  // fused row constants: this lane's half of rowsum(dO * O)
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u};
     if (qrow < N) {
       v = *reinterpret_cast<const u32x4*>(qb + (size_t)qrow * rs + 16 * s + 8 * h);
       w = *reinterpret_cast<const u32x4*>(dout + ((size_t)b * N + qrow) * ostride + (size_t)head * HD + 16 * s + 8 * h);
+      if (o_in != nullptr) {
+        const u32x4 ov = *reinterpret_cast<const u32x4*>(o_in + ((size_t)b * N + qrow) * ostride + (size_t)head * HD + 16 * s + 8 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dpart += bflo(ov[e]) * bflo(w[e]) + bfhi(ov[e]) * bfhi(w[e]);
+      }
     }
     qf[s] = scale_frag(v, sc2);                 // pre-scaled: S^T accumulates in the exp2 domain (used for S only)
     dof[s] = __builtin_bit_cast(bf16x8, w);
   }
-  float nlse2 = 0.f, ndlt = 0.f;      // -lse*log2e and -delta of this lane's query (attn_delta_kernel)
-  if (qrow < N) {
-    nlse2 = rowc[((size_t)b * H + head) * N + qrow];
-    ndlt = rowc[(size_t)gridDim.z * H * N + ((size_t)b * H + head) * N + qrow];
+  // -lse*log2e and -delta of this lane's query: read from rowc (written by attn_delta_kernel), or -- o_in / lse_in given --
+  // computed here from this wave's own O and dO rows and WRITTEN to rowc for the dK/dV kernel that follows: the separate
+  // pre-pass (one more read of O and dO, 29 ms per two steps) goes away.
+  float nlse2 = 0.f, ndlt = 0.f;
+  const size_t rc_i = ((size_t)b * H + head) * N + qrow, rc_plane = (size_t)gridDim.z * H * N;
+  if (o_in != nullptr) {
+    dpart += __shfl_xor(dpart, 32, 64);
+    if (qrow < N) {
+      nlse2 = -lse_in[rc_i] * LOG2E;
+      ndlt = -dpart;
+      if (h == 0) { rowc[rc_i] = nlse2; rowc[rc_plane + rc_i] = ndlt; }
+    }
+  } else if (qrow < N) {
+    nlse2 = rowc[rc_i];
+    ndlt = rowc[rc_plane + rc_i];
   }
 
   f32x16 dq[DB], lse_t, dlt_t;   // row constants replicated over an accumulator tile: out-of-place C operands, set once
@@ -724,10 +742,11 @@ static int run_delta(const bf16_t* o, const bf16_t* dout, const float* lse, floa
   return 0;
 }
 template <int HD>
-static int run_dq(const bf16_t* qkv, const bf16_t* dout, const float* rowc, bf16_t* dqkv, int B, int N, int H, float scale,
-                  hipStream_t st) {
+static int run_dq(const bf16_t* qkv, const bf16_t* dout, float* rowc, bf16_t* dqkv, int B, int N, int H, float scale,
+                  hipStream_t st, const bf16_t* o_in = nullptr, const float* lse_in = nullptr) {
   dim3 grid((N + 127) / 128, H, B);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, grid, dim3(256), 2 * DQ_RING(HD) * Tile<HD>::BYTES, st, qkv, dout, rowc, dqkv, N, H, scale);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, grid, dim3(256), 2 * DQ_RING(HD) * Tile<HD>::BYTES, st, qkv, dout, rowc, dqkv, N, H, scale,
+                     o_in, lse_in);
   OCTMAE_LAUNCH_CHECK();
   return 0;
 }
@@ -765,7 +784,8 @@ extern "C" int octmae_attn_bwd_dq(const void* qkv, const void* dout, const float
   OCTMAE_CHECK_ARG(qkv && dout && rowc && dqkv && B > 0 && N > 0 && H > 0 && (HD == 64 || HD == 32));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   bf16_t* d = reinterpret_cast<bf16_t*>(dqkv);
-  return HD == 64 ? run_dq<64>(BFP(qkv), BFP(dout), rowc, d, B, N, H, scale, st) : run_dq<32>(BFP(qkv), BFP(dout), rowc, d, B, N, H, scale, st);
+  float* rc = const_cast<float*>(rowc);   // only read on this path
+  return HD == 64 ? run_dq<64>(BFP(qkv), BFP(dout), rc, d, B, N, H, scale, st) : run_dq<32>(BFP(qkv), BFP(dout), rc, d, B, N, H, scale, st);
 }
 extern "C" int octmae_attn_bwd_dkv(const void* qkv, const void* dout, const float* rowc, void* dqkv, int B, int N, int H, int HD,
                                    float scale, void* stream) {
@@ -778,9 +798,15 @@ extern "C" int octmae_attn_bwd_dkv(const void* qkv, const void* dout, const floa
 // convenience: the three launches above, in order
 extern "C" int octmae_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* rowc_ws, void* dqkv,
                                int B, int N, int H, int HD, float scale, void* stream) {
-  int rc = octmae_attn_bwd_rowconst(o, dout, lse, rowc_ws, B, N, H, HD, stream);
-  if (rc) return rc;
-  rc = octmae_attn_bwd_dq(qkv, dout, rowc_ws, dqkv, B, N, H, HD, scale, stream);
+  int rc = octmae_attn_bwd_dq_rowconst(qkv, o, dout, lse, rowc_ws, dqkv, B, N, H, HD, scale, stream);
   if (rc) return rc;
   return octmae_attn_bwd_dkv(qkv, dout, rowc_ws, dqkv, B, N, H, HD, scale, stream);
+}
+extern "C" int octmae_attn_bwd_dq_rowconst(const void* qkv, const void* o, const void* dout, const float* lse, float* rowc,
+                                           void* dqkv, int B, int N, int H, int HD, float scale, void* stream) {
+  OCTMAE_CHECK_ARG(qkv && o && dout && lse && rowc && dqkv && B > 0 && N > 0 && H > 0 && (HD == 64 || HD == 32));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  bf16_t* d = reinterpret_cast<bf16_t*>(dqkv);
+  return HD == 64 ? run_dq<64>(BFP(qkv), BFP(dout), rowc, d, B, N, H, scale, st, BFP(o), lse)
+                  : run_dq<32>(BFP(qkv), BFP(dout), rowc, d, B, N, H, scale, st, BFP(o), lse);
 }

@@ -276,12 +276,12 @@ def attn_bwd(qkv, o, dout, lse, B, N, H, HD, scale):
     dqkv = torch.empty_like(qkv)
     rowc = torch.empty((2, B, H, N), dtype=F32, device=qkv.device)      # -lse*log2e | -rowsum(dO * O)
     st = _stream()
-    call("octmae_attn_bwd_rowconst", o.data_ptr(), dout.data_ptr(), lse.data_ptr(), rowc.data_ptr(), B, N, H, HD, st)
-    # algorithmic backward = 5 matmuls (10 B H N^2 HD flop); dq executes 3 of them, dkv 4 (S and dP are recomputed twice)
+    # algorithmic backward = 5 matmuls (10 B H N^2 HD flop); dq executes 3 of them, dkv 4 (S and dP are recomputed twice).
+    # The dQ kernel also produces the row constants (rowc) that the dK/dV kernel reads.
     unit = 2.0 * B * H * N * N * HD
-    _launch(f"attn_bwd_dq_hd{HD}", 2 * unit, 2.0 * 5 * B * N * H * HD,
-            lambda: call("octmae_attn_bwd_dq", qkv.data_ptr(), dout.data_ptr(), rowc.data_ptr(), dqkv.data_ptr(), B, N, H, HD,
-                         float(scale), st))
+    _launch(f"attn_bwd_dq_hd{HD}", 2 * unit, 2.0 * 6 * B * N * H * HD,
+            lambda: call("octmae_attn_bwd_dq_rowconst", qkv.data_ptr(), o.data_ptr(), dout.data_ptr(), lse.data_ptr(), rowc.data_ptr(),
+                         dqkv.data_ptr(), B, N, H, HD, float(scale), st))
     _launch(f"attn_bwd_dkv_hd{HD}", 3 * unit, 2.0 * 6 * B * N * H * HD,
             lambda: call("octmae_attn_bwd_dkv", qkv.data_ptr(), dout.data_ptr(), rowc.data_ptr(), dqkv.data_ptr(), B, N, H, HD,
                          float(scale), st))

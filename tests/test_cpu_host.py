@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
         assert s in _lib.SIGNATURES, f"{s} declared in octmae.h but not bound in _lib.SIGNATURES"
     assert set(_lib.SIGNATURES) == set(syms)
-    assert lib.octmae_abi_version() == 3 and lib.octmae_mt_chunk_elems() == 65536
+    assert lib.octmae_abi_version() == 4 and lib.octmae_mt_chunk_elems() == 65536
 
 
 def test_argument_errors_are_reported_without_a_gpu():

@@ -306,6 +306,36 @@ def test_attention_fwd_bwd(HD, N, optimistic):
             assert rel(got[:, :, i], ref[:, :, i]) < 1.5e-2, name     # bf16 P, dS and outputs
 
 
+@pytest.mark.parametrize("HD,N", [(64, 333), (32, 1281), (64, 129), (32, 64)])
+def test_attention_backward_fused_row_constants(HD, N):
+    """octmae_attn_bwd (dQ kernel computes and publishes the row constants) against the three-launch form
+    rowconst -> dq -> dkv: same gradients (the constants differ only in fp32 summation order), and the published constants
+    equal the pre-pass's."""
+    from octcubem_amd import _lib
+    lib = _lib.load()
+    B, H = 2, 4
+    g = torch.Generator().manual_seed(HD + N)
+    qkv = bf(torch.randn(B * N, 3 * H * HD, generator=g)).to(DEV)
+    do = bf(torch.randn(B * N, H * HD, generator=g)).to(DEV)
+    scale = HD ** -0.5
+    o, lse = ops.attn_fwd(qkv, B, N, H, HD, scale)
+    st = torch.cuda.current_stream().cuda_stream
+    rc3 = torch.zeros(2, B, H, N, dtype=torch.float32, device=DEV)
+    d3 = torch.zeros_like(qkv)
+    assert lib.octmae_attn_bwd_rowconst(o.data_ptr(), do.data_ptr(), lse.data_ptr(), rc3.data_ptr(), B, N, H, HD, st) == 0
+    assert lib.octmae_attn_bwd_dq(qkv.data_ptr(), do.data_ptr(), rc3.data_ptr(), d3.data_ptr(), B, N, H, HD, scale, st) == 0
+    assert lib.octmae_attn_bwd_dkv(qkv.data_ptr(), do.data_ptr(), rc3.data_ptr(), d3.data_ptr(), B, N, H, HD, scale, st) == 0
+    rc1 = torch.zeros(2, B, H, N, dtype=torch.float32, device=DEV)
+    d1 = torch.zeros_like(qkv)
+    assert lib.octmae_attn_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), rc1.data_ptr(), d1.data_ptr(), B, N, H, HD,
+                               scale, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(rc1[0], rc3[0])                                   # -lse * log2e: the same product
+    assert float((rc1[1] - rc3[1]).abs().max()) <= 1e-5 * float(rc3[1].abs().max()) + 1e-6
+    assert rel(d1, d3) < 1e-3
+    assert torch.equal(ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, scale), d1)     # the host wrapper takes the fused path
+
+
 @pytest.mark.parametrize("HD", [64, 32])
 def test_attention_online_softmax_rescale_branch(HD):
     """Force the running max to jump at a late key tile (one query/key pair with a huge score)."""

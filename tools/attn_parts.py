@@ -23,6 +23,7 @@ for name, N, H, HD in SHAPES:
     assert lib.octmae_attn_bwd_rowconst(o.data_ptr(), do.data_ptr(), lse.data_ptr(), rowc.data_ptr(), B, N, H, HD, st) == 0
     unit = 2.0 * B * H * N * N * HD
     tf = t(lambda: ops.attn_fwd(qkv, B, N, H, HD, HD ** -0.5))
-    tq = t(lambda: lib.octmae_attn_bwd_dq(qkv.data_ptr(), do.data_ptr(), rowc.data_ptr(), dqkv.data_ptr(), B, N, H, HD, HD ** -0.5, st))
+    tq = t(lambda: lib.octmae_attn_bwd_dq_rowconst(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), rowc.data_ptr(), dqkv.data_ptr(),
+                                                   B, N, H, HD, HD ** -0.5, st))   # dQ + the row constants
     tk = t(lambda: lib.octmae_attn_bwd_dkv(qkv.data_ptr(), do.data_ptr(), rowc.data_ptr(), dqkv.data_ptr(), B, N, H, HD, HD ** -0.5, st))
     print(f"{name} hd{HD} N={N} B={B}: fwd {tf:8.1f} us {2*unit/tf/1e6:7.1f} TF | dq {tq:8.1f} us {3*unit/tq/1e6:7.1f} TF | dkv {tk:8.1f} us {4*unit/tk/1e6:7.1f} TF", flush=True)
