@@ -20,6 +20,10 @@
 extern "C" {
 #endif
 
+/* The ONE place the ABI number lives: octmae_abi_version() returns it (csrc/probe.hip), octcubem_amd/_lib.py parses it
+ * from this header and refuses a library that reports another number, __graft_entry__.build() and the tests compare the two.
+ * 4: octmae_attn_bwd_dq_rowconst.  5: octmae_comm_* (RCCL), octmae_attn_bwd_fused + workspace query. */
+#define OCTMAE_ABI_VERSION 5
 int octmae_abi_version(void);
 
 /* ---- GEMM with fused epilogues ------------------------------------------------------------------
@@ -133,6 +137,40 @@ int octmae_mt_finish_norm(const float* sumsq, int ntensors, float max_norm, floa
 int octmae_mt_adamw(const void* tensor_table, const int* chunk_tensor, const long long* chunk_off, int nchunks,
                     const float* gscale, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                     void* stream);
+
+/* ---- data-parallel exchange over RCCL (xGMI) -----------------------------------------------------------
+ * What the reference gets from torch.distributed's NCCL backend on this path:
+ *   init_process_group("nccl") + barrier                    Pre-training/custom_util/misc.py:283-296
+ *   DistributedDataParallel: bucketed gradient mean          Pre-training/main_pretrain_oph_joint_2d512_flash_attn.py:434-439
+ *   DDP's constructor broadcast of the parameters            (same wrap site)
+ *   all_reduce_mean of the logged loss                       Pre-training/custom_util/misc.py:622-630
+ *   open_clip's feature all-gather (+ its reduce-scatter backward)   retinal-COEM/src/open_clip/loss.py:51-63
+ * One process per GPU.  Bootstrap: rank 0 calls octmae_comm_unique_id() into a HOST buffer of OCTMAE_COMM_ID_BYTES, the host
+ * side hands those bytes to every rank (the launcher's key-value store: MASTER_ADDR/MASTER_PORT of torchrun), every rank calls
+ * octmae_comm_init().  The handle is opaque and owns one communication stream; it is the one object this library retains
+ * between calls (freed by octmae_comm_destroy).  Every *_async call enqueues ONE collective on the communication stream,
+ * ordered behind everything `after_stream` (the caller's compute stream) holds at the time of the call, and returns without
+ * synchronising the host; octmae_comm_wait() makes `stream` wait for every collective enqueued so far.  In-place (`buf`)
+ * unless send/recv are given.  Calls may come from any host thread (autograd's worker thread reports finished gradient
+ * slices); they are serialised per communicator.  Buffers are DEVICE pointers and must stay alive until a later
+ * octmae_comm_wait()'s stream has passed it.
+ * Return codes: as above, plus -3 = librccl not found at run time, and 10000 + ncclResult_t for an RCCL error. */
+#define OCTMAE_COMM_ID_BYTES 128
+enum { OCTMAE_COMM_F32 = 0, OCTMAE_COMM_BF16 = 1, OCTMAE_COMM_F64 = 2 };
+enum { OCTMAE_COMM_SUM = 0, OCTMAE_COMM_AVG = 1, OCTMAE_COMM_MAX = 2 };
+int octmae_comm_available(void);                       /* 1 when librccl could be loaded, 0 otherwise (never fails) */
+int octmae_comm_unique_id(void* id_bytes_host);
+int octmae_comm_init(void** comm_out, const void* id_bytes_host, int rank, int world, int device);
+int octmae_comm_destroy(void* comm);
+int octmae_comm_rank(void* comm);                      /* plain values, not status codes; -1 for a NULL handle */
+int octmae_comm_world(void* comm);
+int octmae_comm_allreduce_async(void* comm, void* buf, long long count, int dtype, int op, void* after_stream);
+int octmae_comm_broadcast_async(void* comm, void* buf, long long count, int dtype, int root, void* after_stream);
+int octmae_comm_allgather_async(void* comm, const void* send, void* recv, long long count_per_rank, int dtype,
+                                void* after_stream);
+int octmae_comm_reduce_scatter_async(void* comm, const void* send, void* recv, long long count_per_rank, int dtype, int op,
+                                     void* after_stream);
+int octmae_comm_wait(void* comm, void* stream);
 
 /* ---- hardware layout probes (tests only: pin the MFMA / ds_read_b64_tr_b16 lane maps the kernels assume) */
 int octmae_probe_mfma32(const void* a_frag_bf16, const void* b_frag_bf16, float* d_regs, void* stream);

@@ -41,11 +41,32 @@ SIGNATURES = {
     "octmae_mt_sumsq": [_vp, _vp, _vp, _i, _vp, _vp],
     "octmae_mt_finish_norm": [_vp, _i, _f, _vp, _vp, _vp],
     "octmae_mt_adamw": [_vp, _vp, _vp, _i, _vp, _f, _f, _f, _f, _f, _i, _vp],
+    "octmae_comm_available": [],
+    "octmae_comm_unique_id": [_vp],
+    "octmae_comm_init": [_vp, _vp, _i, _i, _i],
+    "octmae_comm_destroy": [_vp],
+    "octmae_comm_rank": [_vp],
+    "octmae_comm_world": [_vp],
+    "octmae_comm_allreduce_async": [_vp, _vp, _ll, _i, _i, _vp],
+    "octmae_comm_broadcast_async": [_vp, _vp, _ll, _i, _i, _vp],
+    "octmae_comm_allgather_async": [_vp, _vp, _vp, _ll, _i, _vp],
+    "octmae_comm_reduce_scatter_async": [_vp, _vp, _vp, _ll, _i, _i, _vp],
+    "octmae_comm_wait": [_vp, _vp],
     "octmae_probe_mfma32": [_vp, _vp, _vp, _vp],
     "octmae_probe_trread": [_vp, _vp, _vp],
 }
 
 _lib = None
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "octmae.h")
+
+
+def expected_abi_version() -> int:
+    """OCTMAE_ABI_VERSION as include/octmae.h defines it -- the single place the number is written."""
+    import re
+    m = re.search(r"^#define\s+OCTMAE_ABI_VERSION\s+(\d+)", open(HEADER_PATH).read(), re.M)
+    if m is None:
+        raise OctmaeError(f"{HEADER_PATH} does not define OCTMAE_ABI_VERSION")
+    return int(m.group(1))
 
 
 class OctmaeError(RuntimeError):
@@ -69,6 +90,9 @@ def load():
             raise OctmaeError(f"liboctmae.so does not export {name}") from e
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    if os.path.exists(HEADER_PATH) and lib.octmae_abi_version() != expected_abi_version():
+        raise OctmaeError(f"{LIB_PATH} reports ABI {lib.octmae_abi_version()}, include/octmae.h declares "
+                          f"{expected_abi_version()}: rebuild (make -C octcubem_amd/csrc)")
     _lib = lib
     return lib
 
@@ -77,6 +101,7 @@ def call(name, *args):
     """Invoke a C-ABI entry point and turn its status code into an exception."""
     rc = getattr(load(), name)(*args)
     if rc != 0:
-        kind = "bad argument" if rc == -1 else "unsupported combination" if rc == -2 else f"hipError_t {rc}"
+        kind = ("bad argument" if rc == -1 else "unsupported combination" if rc == -2 else "librccl not found" if rc == -3
+                else f"ncclResult_t {rc - 10000}" if rc >= 10000 else f"hipError_t {rc}")
         raise OctmaeError(f"{name} failed: {kind} (rc={rc})")
     return rc

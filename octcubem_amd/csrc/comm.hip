@@ -1,0 +1,258 @@
+// Data-parallel exchange over RCCL (xGMI inside one MI355X node) behind the C ABI: octmae_comm_*.
+//
+// Replaces, for the hot path, what the reference gets from torch.distributed's NCCL backend:
+//   init_process_group("nccl") + barrier              Pre-training/custom_util/misc.py:283-296
+//   DistributedDataParallel's bucketed gradient mean   Pre-training/main_pretrain_oph_joint_2d512_flash_attn.py:434-439
+//   DDP's constructor broadcast of the parameters      (torch.nn.parallel.DistributedDataParallel ctor)
+//   all_reduce_mean of the logged loss                 Pre-training/custom_util/misc.py:622-630
+//
+// One process per GPU.  A communicator owns ONE communication stream and two events; every collective is enqueued on that
+// stream behind an event recorded on the caller's (compute) stream, so it runs beside the rest of backward, and
+// octmae_comm_wait() makes a stream wait for everything enqueued so far (the optimizer waits for the last chunk this way).
+// Calls arrive from the main thread and from autograd's worker thread (backward Functions report finished gradient slices):
+// they are serialised by a mutex per communicator; there is no thread-local state.
+//
+// librccl is resolved at run time (dlopen "librccl.so.1", i.e. the copy PyTorch-ROCm has already mapped when the caller is the
+// Python host, /opt/rocm/lib's otherwise): liboctmae.so keeps loading on a box without RCCL, and the compute entry points do
+// not depend on it.  Only the handful of RCCL entry points below are used.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+#include <new>
+
+#include "../../include/octmae.h"
+
+namespace {
+
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
+  bool ok = false;
+};
+
+std::mutex g_load_mu;
+Rccl g_rccl;
+
+// 0 ok, -3 library or symbol missing
+int load_rccl() {
+  std::lock_guard<std::mutex> lk(g_load_mu);
+  if (g_rccl.ok) return 0;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names) {
+    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) return -3;
+  Rccl r;
+  r.lib = h;
+#define OCTMAE_SYM(field, sym)                                          \
+  r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, sym));         \
+  if (!r.field) return -3;
+  OCTMAE_SYM(GetUniqueId, "ncclGetUniqueId")
+  OCTMAE_SYM(CommInitRank, "ncclCommInitRank")
+  OCTMAE_SYM(CommDestroy, "ncclCommDestroy")
+  OCTMAE_SYM(AllReduce, "ncclAllReduce")
+  OCTMAE_SYM(Broadcast, "ncclBroadcast")
+  OCTMAE_SYM(AllGather, "ncclAllGather")
+  OCTMAE_SYM(ReduceScatter, "ncclReduceScatter")
+  OCTMAE_SYM(GetVersion, "ncclGetVersion")
+#undef OCTMAE_SYM
+  r.ok = true;
+  g_rccl = r;
+  return 0;
+}
+
+struct Comm {
+  ncclComm_t comm = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  int rank = 0, world = 1, device = 0;
+  std::mutex mu;
+};
+
+constexpr int NCCL_ERR_BASE = 10000;   // ncclResult_t r != ncclSuccess is reported as NCCL_ERR_BASE + r
+
+struct DeviceGuard {                   // HIP's current device is per host thread
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+    else prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+#define HIP_TRY(x)                          \
+  do {                                      \
+    hipError_t e__ = (x);                   \
+    if (e__ != hipSuccess) return (int)e__; \
+  } while (0)
+#define NCCL_TRY(x)                                         \
+  do {                                                      \
+    ncclResult_t r__ = (x);                                 \
+    if (r__ != ncclSuccess) return NCCL_ERR_BASE + (int)r__; \
+  } while (0)
+
+// order the communication stream behind what `after` (the caller's stream) has enqueued so far
+int chain_in(Comm* c, void* after) {
+  HIP_TRY(hipEventRecord(c->ev_in, reinterpret_cast<hipStream_t>(after)));
+  HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+  return 0;
+}
+
+bool dtype_of(int dtype, ncclDataType_t* t) {
+  switch (dtype) {
+    case OCTMAE_COMM_F32: *t = ncclFloat32; return true;
+    case OCTMAE_COMM_BF16: *t = ncclBfloat16; return true;
+    case OCTMAE_COMM_F64: *t = ncclFloat64; return true;
+    default: return false;
+  }
+}
+bool op_of(int op, ncclRedOp_t* o) {
+  switch (op) {
+    case OCTMAE_COMM_SUM: *o = ncclSum; return true;
+    case OCTMAE_COMM_AVG: *o = ncclAvg; return true;
+    case OCTMAE_COMM_MAX: *o = ncclMax; return true;
+    default: return false;
+  }
+}
+
+}  // namespace
+
+extern "C" int octmae_comm_available(void) { return load_rccl() == 0 ? 1 : 0; }
+
+extern "C" int octmae_comm_unique_id(void* id_bytes_host) {
+  if (!id_bytes_host) return -1;
+  if (int rc = load_rccl()) return rc;
+  static_assert(sizeof(ncclUniqueId) == OCTMAE_COMM_ID_BYTES, "OCTMAE_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");
+  ncclUniqueId id;
+  NCCL_TRY(g_rccl.GetUniqueId(&id));
+  __builtin_memcpy(id_bytes_host, &id, sizeof(id));
+  return 0;
+}
+
+extern "C" int octmae_comm_init(void** comm_out, const void* id_bytes_host, int rank, int world, int device) {
+  if (!comm_out || !id_bytes_host || world < 1 || rank < 0 || rank >= world || device < 0) return -1;
+  if (int rc = load_rccl()) return rc;
+  Comm* c = new (std::nothrow) Comm();
+  if (!c) return -1;
+  c->rank = rank; c->world = world; c->device = device;
+  DeviceGuard g(device);
+  ncclUniqueId id;
+  __builtin_memcpy(&id, id_bytes_host, sizeof(id));
+  int rc = 0;
+  do {
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { rc = (int)e; break; }
+    e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
+    if (e != hipSuccess) { rc = (int)e; break; }
+    e = hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming);
+    if (e != hipSuccess) { rc = (int)e; break; }
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) { rc = NCCL_ERR_BASE + (int)r; break; }
+  } while (0);
+  if (rc != 0) {
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    if (c->ev_out) (void)hipEventDestroy(c->ev_out);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return rc;
+  }
+  *comm_out = c;
+  return 0;
+}
+
+extern "C" int octmae_comm_destroy(void* comm) {
+  if (!comm) return -1;
+  Comm* c = reinterpret_cast<Comm*>(comm);
+  int rc = 0;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = (int)e;
+    ncclResult_t r = g_rccl.CommDestroy(c->comm);
+    if (r != ncclSuccess && rc == 0) rc = NCCL_ERR_BASE + (int)r;
+    (void)hipEventDestroy(c->ev_in);
+    (void)hipEventDestroy(c->ev_out);
+    (void)hipStreamDestroy(c->stream);
+  }
+  delete c;
+  return rc;
+}
+
+extern "C" int octmae_comm_rank(void* comm) { return comm ? reinterpret_cast<Comm*>(comm)->rank : -1; }
+extern "C" int octmae_comm_world(void* comm) { return comm ? reinterpret_cast<Comm*>(comm)->world : -1; }
+
+extern "C" int octmae_comm_allreduce_async(void* comm, void* buf, long long count, int dtype, int op, void* after_stream) {
+  if (!comm || !buf || count <= 0) return -1;
+  ncclDataType_t t; ncclRedOp_t o;
+  if (!dtype_of(dtype, &t) || !op_of(op, &o)) return -2;
+  Comm* c = reinterpret_cast<Comm*>(comm);
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  if (int rc = chain_in(c, after_stream)) return rc;
+  NCCL_TRY(g_rccl.AllReduce(buf, buf, (size_t)count, t, o, c->comm, c->stream));
+  return 0;
+}
+
+extern "C" int octmae_comm_broadcast_async(void* comm, void* buf, long long count, int dtype, int root, void* after_stream) {
+  if (!comm || !buf || count <= 0) return -1;
+  ncclDataType_t t;
+  if (!dtype_of(dtype, &t)) return -2;
+  Comm* c = reinterpret_cast<Comm*>(comm);
+  if (root < 0 || root >= c->world) return -1;
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  if (int rc = chain_in(c, after_stream)) return rc;
+  NCCL_TRY(g_rccl.Broadcast(buf, buf, (size_t)count, t, root, c->comm, c->stream));
+  return 0;
+}
+
+extern "C" int octmae_comm_allgather_async(void* comm, const void* send, void* recv, long long count_per_rank, int dtype,
+                                           void* after_stream) {
+  if (!comm || !send || !recv || count_per_rank <= 0) return -1;
+  ncclDataType_t t;
+  if (!dtype_of(dtype, &t)) return -2;
+  Comm* c = reinterpret_cast<Comm*>(comm);
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  if (int rc = chain_in(c, after_stream)) return rc;
+  NCCL_TRY(g_rccl.AllGather(send, recv, (size_t)count_per_rank, t, c->comm, c->stream));
+  return 0;
+}
+
+extern "C" int octmae_comm_reduce_scatter_async(void* comm, const void* send, void* recv, long long count_per_rank, int dtype,
+                                                int op, void* after_stream) {
+  if (!comm || !send || !recv || count_per_rank <= 0) return -1;
+  ncclDataType_t t; ncclRedOp_t o;
+  if (!dtype_of(dtype, &t) || !op_of(op, &o)) return -2;
+  Comm* c = reinterpret_cast<Comm*>(comm);
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  if (int rc = chain_in(c, after_stream)) return rc;
+  NCCL_TRY(g_rccl.ReduceScatter(send, recv, (size_t)count_per_rank, t, o, c->comm, c->stream));
+  return 0;
+}
+
+extern "C" int octmae_comm_wait(void* comm, void* stream) {
+  if (!comm) return -1;
+  Comm* c = reinterpret_cast<Comm*>(comm);
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  HIP_TRY(hipEventRecord(c->ev_out, c->stream));
+  HIP_TRY(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), c->ev_out, 0));
+  return 0;
+}

@@ -148,6 +148,28 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 
 }  // namespace octmae
 
+// ---- hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) --------------------------------------------
+// One object per kernel (a function-local static in its launcher).  The attribute is per device, so the "done" state is a bit
+// per device ordinal, set with an atomic OR: concurrent first calls from the forward thread and autograd's backward thread
+// both set the (idempotent) attribute and both succeed -- no thread-local or unsynchronised state behind the C ABI.
+#include <atomic>
+namespace octmae {
+struct DynLdsOnce {
+  std::atomic<unsigned long long> done{0};
+  int ensure(const void* fn, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    done.fetch_or(bit, std::memory_order_release);
+    return 0;
+  }
+};
+}  // namespace octmae
+
 // ---- host-side error plumbing for the C ABI ---------------------------------------------------
 #define OCTMAE_CHECK_ARG(cond) \
   do {                         \

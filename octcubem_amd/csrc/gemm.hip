@@ -823,12 +823,8 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const GemmParams p) {
 template <bool A_KS, bool B_KS, int EPI, bool OUT_AB>
 static int launch256(const GemmParams& p, int splitk, hipStream_t st, bool phased) {
   auto kern = phased ? gemm256p_kernel<A_KS, B_KS, EPI, OUT_AB> : gemm256_kernel<A_KS, B_KS, EPI, OUT_AB>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[phased]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set[phased] = true;
-  }
+  static DynLdsOnce once[2];
+  if (int rc = once[phased].ensure(reinterpret_cast<const void*>(kern), 4 * TILE2_BYTES)) return rc;
   dim3 grid(p.tiles_a * p.tiles_b, 1, splitk);
   hipLaunchKernelGGL(kern, grid, dim3(512), 4 * TILE2_BYTES, st, p);
   OCTMAE_LAUNCH_CHECK();
@@ -838,12 +834,8 @@ static int launch256(const GemmParams& p, int splitk, hipStream_t st, bool phase
 template <bool A_KS, bool B_KS, int EPI, bool OUT_AB>
 static int launch(const GemmParams& p, int splitk, hipStream_t st) {
   auto kern = gemm_kernel<A_KS, B_KS, EPI, OUT_AB>;
-  static bool attr_set = false;  // benign race: idempotent
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static DynLdsOnce once;
+  if (int rc = once.ensure(reinterpret_cast<const void*>(kern), 4 * TILE_BYTES)) return rc;
   dim3 grid(p.tiles_a * p.tiles_b, 1, splitk);
   hipLaunchKernelGGL(kern, grid, dim3(256), 4 * TILE_BYTES, st, p);
   OCTMAE_LAUNCH_CHECK();

@@ -56,12 +56,8 @@ extern "C" int octmae_random_masking_ids(const float* noise, long long* ids_rest
   int npad = 2;
   while (npad < L) npad <<= 1;
   const size_t lds = (size_t)npad * 8;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mask_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static DynLdsOnce once;
+  if (int rc = once.ensure(reinterpret_cast<const void*>(mask_sort_kernel), 16384 * 8)) return rc;
   hipLaunchKernelGGL(mask_sort_kernel, dim3(B), dim3(1024), lds, reinterpret_cast<hipStream_t>(stream), noise, ids_restore,
                      ids_keep, ids_shuffle, mask, L, npad, len_keep);
   OCTMAE_LAUNCH_CHECK();

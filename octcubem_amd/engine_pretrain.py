@@ -106,12 +106,13 @@ def train_one_epoch_joint(model: torch.nn.Module, data_loader: Iterable, optimiz
     losses summed before a single backward; the 2-D loader restarts when exhausted.  ``data_loader`` yields
     ``(samples, (img_names, data_dict))``.  Same omissions as ``train_one_epoch`` (the dropped ``get_mask`` result, the
     per-iteration device synchronise); ``fp32`` / ``fp16`` are accepted and ignored (bf16 operands, fp32 everything else).
-    Both forwards feed the same parameters, so a data-parallel reducer exchanges gradients after backward, not during."""
+    Both forwards feed the same parameters, so a parameter reports its gradient once per use: the data-parallel reducer learns
+    the number of reports per parameter in the first exchanged backward (run without overlap) and overlaps from then on."""
     model.train(True)
     net = getattr(model, "module", model)
     reducer = getattr(loss_scaler, "reducer", None)
     if reducer is not None:
-        reducer.overlap = False
+        reducer.multi_use = True
     metric_logger = misc.MetricLogger(delimiter="  ")
     for name in ("lr", "mask_ratio", "mask_ratio_2d"):
         metric_logger.add_meter(name, misc.SmoothedValue(window_size=1, fmt="{value:.6f}"))

@@ -70,11 +70,23 @@ def init_distributed_mode(args):
     print(f"| distributed init (rank {args.rank}): {args.dist_url}, gpu {args.gpu}", flush=True)
     dist.init_process_group(backend=backend, init_method=args.dist_url, world_size=args.world_size, rank=args.rank,
                             timeout=datetime.timedelta(seconds=1800))
-    dist.barrier()
+    args.comm = None
+    if backend == "nccl":
+        # data plane: the library's own RCCL communicator (octmae_comm_*); torch.distributed stays the control plane -- its
+        # store carries the RCCL unique id, and its NCCL communicator is never created unless somebody issues a dist collective
+        from . import comm as _comm
+        args.comm = _comm.NativeComm.from_store(dist.distributed_c10d._get_default_store(), args.rank, args.world_size, args.gpu)
+        _comm.set_default(args.comm)
+        args.comm.barrier()
+    else:
+        dist.barrier()
 
 
 def all_reduce_mean(x):
     world_size = get_world_size()
+    from . import comm as _comm
+    if _comm.get_default() is not None and _comm.get_default().world > 1:
+        return _comm.get_default().all_reduce_scalar(float(x), _comm.AVG)
     if world_size > 1:
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
         x_reduce = torch.tensor(x, dtype=torch.float32, device=dev)

@@ -79,10 +79,12 @@ class KernelTimer:
         self.records = {}
         self.stats = {}
 
-    def launch(self, kind, flops, nbytes, fn):
-        st = self.stats.setdefault(kind, [0, 0.0, 0.0])
+    def launch(self, kind, flops, nbytes, fn, exec_flops=None):
+        """flops: ALGORITHMIC (SURVEY 8d: attention forward 4 B H N^2 hd, backward 8 B H N^2 hd = x3 in total);
+        exec_flops: what the kernel executes (recomputed products included), defaults to flops."""
+        st = self.stats.setdefault(kind, [0, 0.0, 0.0, 0.0])
         sampled = st[0] % self.stride == 0
-        st[0] += 1; st[1] += flops; st[2] += nbytes
+        st[0] += 1; st[1] += flops; st[2] += nbytes; st[3] += flops if exec_flops is None else exec_flops
         if not sampled:
             fn()
             return
@@ -96,22 +98,22 @@ class KernelTimer:
         torch.cuda.synchronize()
         out = {}
         for kind, recs in self.records.items():
-            n, flops, nbytes = self.stats[kind]
+            n, flops, nbytes, xflops = self.stats[kind]
             ms = sum(s.elapsed_time(e) for s, e in recs)
             avg_us = 1e3 * ms / len(recs)
             out[kind] = {"launches": n, "sampled": len(recs), "total_ms": avg_us * n * 1e-3, "avg_us": avg_us, "flops": flops,
-                         "bytes": nbytes}
+                         "bytes": nbytes, "exec_flops": xflops}
         return out
 
 
 KTIMER: Optional[KernelTimer] = None
 
 
-def _launch(kind, flops, nbytes, fn):
+def _launch(kind, flops, nbytes, fn, exec_flops=None):
     if KTIMER is None:
         fn()
     else:
-        KTIMER.launch(kind, flops, nbytes, fn)
+        KTIMER.launch(kind, flops, nbytes, fn, exec_flops)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -276,15 +278,16 @@ def attn_bwd(qkv, o, dout, lse, B, N, H, HD, scale):
     dqkv = torch.empty_like(qkv)
     rowc = torch.empty((2, B, H, N), dtype=F32, device=qkv.device)      # -lse*log2e | -rowsum(dO * O)
     st = _stream()
-    # algorithmic backward = 5 matmuls (10 B H N^2 HD flop); dq executes 3 of them, dkv 4 (S and dP are recomputed twice).
-    # The dQ kernel also produces the row constants (rowc) that the dK/dV kernel reads.
+    # Algorithmic backward ("x3"): 4 matmuls = 8 B H N^2 HD flop (dP, dV, dK, dQ; the recomputation of S is not
+    # counted).  The two-kernel form executes 7: dq 3 (S, dP, dQ), dkv 4 (S, dP, dV, dK); the algorithmic 4 are booked
+    # 1.6 / 2.4 in proportion.  The dQ kernel also produces the row constants (rowc) that the dK/dV kernel reads.
     unit = 2.0 * B * H * N * N * HD
-    _launch(f"attn_bwd_dq_hd{HD}", 2 * unit, 2.0 * 6 * B * N * H * HD,
+    _launch(f"attn_bwd_dq_hd{HD}", 1.6 * unit, 2.0 * 6 * B * N * H * HD,
             lambda: call("octmae_attn_bwd_dq_rowconst", qkv.data_ptr(), o.data_ptr(), dout.data_ptr(), lse.data_ptr(), rowc.data_ptr(),
-                         dqkv.data_ptr(), B, N, H, HD, float(scale), st))
-    _launch(f"attn_bwd_dkv_hd{HD}", 3 * unit, 2.0 * 6 * B * N * H * HD,
+                         dqkv.data_ptr(), B, N, H, HD, float(scale), st), exec_flops=3 * unit)
+    _launch(f"attn_bwd_dkv_hd{HD}", 2.4 * unit, 2.0 * 6 * B * N * H * HD,
             lambda: call("octmae_attn_bwd_dkv", qkv.data_ptr(), dout.data_ptr(), rowc.data_ptr(), dqkv.data_ptr(), B, N, H, HD,
-                         float(scale), st))
+                         float(scale), st), exec_flops=4 * unit)
     return dqkv
 
 

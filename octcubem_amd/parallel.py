@@ -2,19 +2,22 @@
 (wrap site main_pretrain_oph_joint_2d512_flash_attn.py:434-439) with a reducer designed around one flat fp32
 gradient arena and RCCL over xGMI.
 
-  * one process per GPU (torchrun), ``torch.distributed`` backend "nccl" == RCCL on ROCm;
+  * one process per GPU (torchrun); on the GPU the collectives go through the library's own RCCL communicator
+    (``comm.NativeComm`` -> ``octmae_comm_*`` in include/octmae.h), on its own stream; ``torch.distributed`` is used
+    for CPU tests (gloo) and as an explicit, logged fall-back when no native communicator is given;
   * gradients already live in one contiguous arena (arena.ParamArena), so a "bucket" is just a slice:
-    no flatten/unflatten copies;
-  * the arena is cut into a few large contiguous chunks (default 8, ~166 MB each for ViT-L): xGMI is
-    point-to-point (7 links x ~153 GB/s), ring collectives are per-link bound, and large messages amortise the
-    per-collective latency better than DDP's 25 MB buckets;
-  * a chunk is all-reduced on a dedicated communication stream as soon as every parameter in it has reported its
-    gradient (ops.notify_grad_ready, fired by the backward Functions; autograd hooks for the few PyTorch-side
-    parameters), i.e. overlapped with the rest of backward;
+    no flatten/unflatten copies, and the mean is RCCL's own ``ncclAvg`` (no pre-scaling pass over the arena);
+  * the arena is cut into a few large contiguous chunks (~8, ~166 MB each for ViT-L): xGMI is point-to-point
+    (7 links x ~153 GB/s), ring collectives are per-link bound, and large messages amortise the per-collective
+    latency better than DDP's 25 MB buckets;
+  * a chunk is all-reduced as soon as every parameter in it has reported its gradient (ops.notify_grad_ready, fired by
+    the backward Functions; autograd hooks for the few PyTorch-side parameters), i.e. overlapped with the rest of backward;
+  * chunks follow READINESS, not just offsets: parameters that reported no gradient in the previous exchanged backward
+    (``high_res_patch_embed`` on 256x256 input) are cut out into chunks of their own, so they no longer hold
+    back the ~166 MB slice they sit in; those "cold" chunks (3 MB for ViT-L) are exchanged in finish() -- zeros unless this
+    backward did use them, which is why they cannot simply be launched up front;
   * with gradient accumulation the exchange happens only on the LAST micro-step (the reference all-reduces on every
-    micro-step, engine_pretrain.py:163-170 -- identical result, 1/accum_iter the traffic);
-  * parameters that receive no gradient (high_res_patch_embed on 256x256 input) are simply zeros in
-    the arena -- no find_unused_parameters machinery is needed.
+    micro-step, engine_pretrain.py:163-170 -- identical result, 1/accum_iter the traffic).
 Works on CPU with the gloo backend for tests (then the "stream" is the caller's thread).
 """
 from __future__ import annotations
@@ -29,10 +32,14 @@ from . import ops
 
 class FlatGradReducer:
     def __init__(self, model, n_chunks: int = 8, process_group=None, average: bool = True, overlap: bool = True,
-                 force: bool = False):
+                 force: bool = False, comm=None):
         self.model = model
         self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.comm = comm            # comm.NativeComm (GPU) or None (torch.distributed)
+        if comm is not None:
+            self.world = comm.world
+        else:
+            self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
         self.n_chunks = n_chunks
         self.overlap = overlap      # False: exchange everything in finish() (needed when a parameter is used twice per backward)
@@ -42,41 +49,66 @@ class FlatGradReducer:
         self._pending: List = []
         self._hooks = []
         self._comm_stream = None
+        self._cold = frozenset()    # ids of parameters that reported nothing in the last exchanged backward
+        self._seen = set()
+        # A parameter used by SEVERAL forwards of one backward (the joint 3-D + 2-D/512 loop) reports once per use, and its
+        # chunk may only go out after the last report.  multi_use = True: the first exchanged backward runs without overlap
+        # and counts the reports per parameter; later backwards expect exactly those counts (one more is an error, raised).
+        self.multi_use = False
+        self._expected = None       # id(param) -> reports per backward, learned
+        self._reports = {}
+        self.stats = {"launched_in_backward": 0, "launched_in_finish": 0, "bytes_in_finish": 0, "bytes_total": 0}
 
     # ------------------------------------------------------------------ layout
-    def _layout(self):
+    def _layout(self, rebuild: bool = False):
         arena = self.model.arena if hasattr(self.model, "arena") else None
         if arena is None:
             raise RuntimeError("FlatGradReducer needs a model with a flat gradient arena")
-        if arena is self._arena:
+        if arena is self._arena and not rebuild:
             return
+        new_arena = arena is not self._arena
         self._arena = arena
         total = arena.total
         per = (total + self.n_chunks - 1) // self.n_chunks
         per = (per + 1023) // 1024 * 1024
-        self.bounds = [(s, min(s + per, total)) for s in range(0, total, per)]
+        # Cut points: every `per` elements, plus the borders of each run of cold parameters (rounded outwards to the entries'
+        # own offsets, which are 64-element aligned), so that a cold run is a chunk of its own.
+        ents = [(o, n, p) for _, p, o, n in arena.entries if p.requires_grad]
+        cuts = {0, total}
+        cuts.update(range(per, total, per))
+        for i, (o, n, p) in enumerate(ents):
+            cold = id(p) in self._cold
+            prev_cold = i > 0 and id(ents[i - 1][2]) in self._cold
+            if cold != prev_cold and i > 0:
+                cuts.add(o)
+        cuts = sorted(cuts)
+        self.bounds = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+        starts = [a for a, _ in self.bounds]
+        import bisect
+        self._chunk_index = lambda off: max(0, bisect.bisect_right(starts, off) - 1)
         self.chunk_of = {}
         self.remaining_init = [0] * len(self.bounds)
-        for name, p, o, n in arena.entries:
-            if not p.requires_grad:
-                continue
-            cs = sorted({self._chunk_index(o), self._chunk_index(o + n - 1)})
-            cs = list(range(cs[0], cs[-1] + 1))
+        self.cold_chunk = [True] * len(self.bounds)
+        for o, n, p in ents:
+            c0, c1 = self._chunk_index(o), self._chunk_index(o + n - 1)
+            cs = list(range(c0, c1 + 1))
             self.chunk_of[id(p)] = cs
             for c in cs:
                 self.remaining_init[c] += 1
-        for h in self._hooks:
-            h.remove()
-        self._hooks = []
-        for name, p, o, n in arena.entries:
-            if p.requires_grad:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._autograd_hook))
-        if arena.grad.is_cuda and self._comm_stream is None:
+                if id(p) not in self._cold:
+                    self.cold_chunk[c] = False
+        for c in range(len(self.bounds)):
+            if self.remaining_init[c] == 0:
+                self.cold_chunk[c] = True       # padding only
+        if new_arena:
+            for h in self._hooks:
+                h.remove()
+            self._hooks = []
+            for name, p, o, n in arena.entries:
+                if p.requires_grad:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._autograd_hook))
+        if arena.grad.is_cuda and self.comm is None and self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=arena.grad.device)
-
-    def _chunk_index(self, off: int) -> int:
-        per = self.bounds[0][1] - self.bounds[0][0]
-        return min(off // per, len(self.bounds) - 1)
 
     # ------------------------------------------------------------------ per-step protocol
     def begin_backward(self, sync: bool = True):
@@ -87,17 +119,37 @@ class FlatGradReducer:
         self._seen = set()
         self._launched = [False] * len(self.bounds)
         self._pending = []
-        ops.set_grad_ready_callback(self._on_ready if (self._sync and self.overlap) else None)
+        self._in_backward = True
+        self._reports = {}
+        self._overlap_now = self._sync and self.overlap and not (self.multi_use and self._expected is None)
+        ops.set_grad_ready_callback(self._on_ready if self._overlap_now else self._on_ready_note)
 
     def _autograd_hook(self, p):
-        if self._sync and self.overlap:
+        if getattr(self, "_overlap_now", False):
             self._on_ready([p])
+        else:
+            self._on_ready_note([p])
+
+    def _on_ready_note(self, params):          # no overlap: only remember who reported, and how often
+        for p in params:
+            self._seen.add(id(p))
+            self._reports[id(p)] = self._reports.get(id(p), 0) + 1
 
     def _on_ready(self, params):
         for p in params:
             k = id(p)
-            if k in self._seen or k not in self.chunk_of:
+            if k not in self.chunk_of:
                 continue
+            n = self._reports.get(k, 0) + 1
+            self._reports[k] = n
+            exp = 1 if not self.multi_use else self._expected.get(k, 1)
+            if n < exp:
+                continue
+            if n > exp:
+                if self.multi_use:
+                    raise RuntimeError("FlatGradReducer: a parameter reported more gradient contributions in this backward than "
+                                       "in the one its schedule was learned from; its slice may already have been exchanged")
+                continue                       # single-use mode: repeated reports of one Function are harmless duplicates
             self._seen.add(k)
             for c in self.chunk_of[k]:
                 self._remaining[c] -= 1
@@ -110,34 +162,63 @@ class FlatGradReducer:
         self._launched[c] = True
         s, e = self.bounds[c]
         buf = self._arena.grad[s:e]
-        if buf.is_cuda:
+        nbytes = 4 * (e - s)
+        self.stats["bytes_total"] += nbytes
+        if self._in_backward:
+            self.stats["launched_in_backward"] += 1
+        else:
+            self.stats["launched_in_finish"] += 1
+            self.stats["bytes_in_finish"] += nbytes
+        if self.comm is not None:
+            from . import comm as C
+            self.comm.all_reduce_async(buf, C.AVG if self.average else C.SUM)
+        elif buf.is_cuda:
             self._comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._comm_stream):
-                if self.average:
-                    buf.mul_(1.0 / self.world)
-                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                work = dist.all_reduce(buf, op=dist.ReduceOp.AVG if self.average else dist.ReduceOp.SUM, group=self.group,
+                                       async_op=True)
             self._pending.append(work)
         else:
             if self.average:
-                buf.mul_(1.0 / self.world)
+                buf.mul_(1.0 / self.world)      # gloo has no AVG
             self._pending.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Call after backward, before the optimizer: launches whatever has not been exchanged yet (parameters that
         received no gradient this step) and makes the compute stream wait for the communication stream."""
         ops.set_grad_ready_callback(None)
+        self._in_backward = False
         if not self._sync:
             return
         for c in range(len(self.bounds)):
             self._launch(c)
+        if self.comm is not None:
+            self.comm.wait()
         for w in self._pending:
             w.wait()
         if self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
         self._pending = []
+        if self.multi_use and self._expected is None:
+            self._expected = dict(self._reports)
+        # readiness statistics for the next step's chunk layout: whoever did not report is "cold"
+        if self.overlap:
+            cold = frozenset(k for k in self.chunk_of if k not in self._seen)
+            if cold != self._cold:
+                self._cold = cold
+                self._layout(rebuild=True)
+
+    def exposed_bytes_last_step(self) -> int:
+        """Bytes whose all-reduce could only start in finish() (nothing of backward left to hide it), summed over all steps
+        so far; divide by the number of exchanged steps."""
+        return self.stats["bytes_in_finish"]
 
     def broadcast_parameters(self, src: int = 0):
         """DDP's constructor broadcast: make every rank start from rank `src`'s weights (one collective)."""
         self._layout()
         if self.world > 1 or self.force:
-            dist.broadcast(self._arena.flat, src=src, group=self.group)
+            if self.comm is not None:
+                self.comm.broadcast_async(self._arena.flat, src)
+                self.comm.wait()
+            else:
+                dist.broadcast(self._arena.flat, src=src, group=self.group)

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
         assert s in _lib.SIGNATURES, f"{s} declared in octmae.h but not bound in _lib.SIGNATURES"
     assert set(_lib.SIGNATURES) == set(syms)
-    assert lib.octmae_abi_version() == 4 and lib.octmae_mt_chunk_elems() == 65536
+    assert lib.octmae_abi_version() == _lib.expected_abi_version() and lib.octmae_mt_chunk_elems() == 65536
 
 
 def test_argument_errors_are_reported_without_a_gpu():
@@ -171,3 +171,15 @@ def test_lr_decay_groups_match_reference_golden(golden_dir):
         assert a["weight_decay"] == b["weight_decay"] and abs(a["lr_scale"] - b["lr_scale"]) < 1e-15
     for n, lid in json.loads(str(z["layer_ids"])).items():
         assert lr_decay.get_layer_id_for_vit(n, cfg.depth + 1) == lid
+
+
+def test_graft_entry_build_compiles_and_agrees_on_the_abi_number():
+    """__graft_entry__.build() must run clean from this tree: make (a no-op when up to date), import, and the ABI number
+    the library reports == OCTMAE_ABI_VERSION in include/octmae.h (the one place it is written)."""
+    import __graft_entry__ as g
+    from octcubem_amd import _lib
+    g.build()
+    hdr = open(os.path.join(ROOT, "include", "octmae.h")).read()
+    assert int(re.search(r"#define\s+OCTMAE_ABI_VERSION\s+(\d+)", hdr).group(1)) == _lib.load().octmae_abi_version()
+    src = open(os.path.join(ROOT, "octcubem_amd", "csrc", "probe.hip")).read()
+    assert "return OCTMAE_ABI_VERSION" in src

@@ -1,0 +1,174 @@
+"""GPU tests of the RCCL layer behind the C ABI (octmae_comm_*, include/octmae.h) and of FlatGradReducer on top of it.
+
+One GPU is enough for the first group: a ONE-RANK communicator goes through the same ncclCommInitRank / ncclAllReduce /
+stream-and-event path as an 8-rank one (the collective itself degenerates to a copy), so it checks the bootstrap, the stream
+ordering (`after_stream` -> communication stream -> octmae_comm_wait) and the reducer's slice bookkeeping.
+The second group needs >= 2 GPUs on the box and is skipped otherwise: a fresh torchrun child (started at COLLECTION time,
+before this process touches the GPU) runs tests/dp_worker.py on 2 ranks and compares the exchanged gradients with the mean of
+the two ranks' local gradients computed in one process.
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# ---- 2-rank child, launched before anything in this process initialises the GPU (device_count() does not) -------------------
+_CHILD = None
+_CHILD_OUT = None
+if os.environ.get("OCTMAE_SKIP_2GPU_TEST") is None and torch.cuda.device_count() >= 2:
+    _CHILD_OUT = tempfile.mkdtemp(prefix="octmae_dp_")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OCTMAE_DP_OUT=_CHILD_OUT)
+    _CHILD = subprocess.Popen(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", "29617", os.path.join(ROOT, "tests", "dp_worker.py")],
+        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+
+if torch.cuda.is_available():
+    from octcubem_amd import comm as ocomm, models_mae, misc, optim as foptim
+    from octcubem_amd.parallel import FlatGradReducer
+from oracle import mae3d_ref as O
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def comm1():
+    assert ocomm.available(), "librccl could not be loaded"
+    c = ocomm.NativeComm(ocomm.NativeComm.unique_id(), 0, 1, 0)
+    yield c
+    c.destroy()
+
+
+def test_one_rank_collectives_are_identities(comm1):
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(1 << 20, device=DEV, generator=g)
+    for op in (ocomm.SUM, ocomm.AVG, ocomm.MAX):
+        y = x.clone()
+        comm1.all_reduce_async(y, op)
+        comm1.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(y, x)
+    y = x.clone()
+    comm1.broadcast_async(y, 0)
+    comm1.wait()
+    out = torch.empty_like(x)
+    comm1.all_gather_async(x, out)
+    rs = torch.empty_like(x)
+    comm1.reduce_scatter_async(x, rs, ocomm.SUM)
+    comm1.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(y, x) and torch.equal(out, x) and torch.equal(rs, x)
+    xb = x.to(torch.bfloat16)
+    yb = xb.clone()
+    comm1.all_reduce_async(yb, ocomm.SUM)
+    comm1.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(yb, xb)
+    assert comm1.all_reduce_scalar(3.25, ocomm.MAX) == 3.25
+    comm1.barrier()
+
+
+def test_collective_is_ordered_behind_the_callers_stream_and_wait_orders_the_consumer(comm1):
+    """The all-reduce must see what the compute stream wrote BEFORE the call, and work enqueued on the compute stream AFTER
+    wait() must see the collective's result -- with a long-running producer in front so that a missing dependency shows."""
+    n = 1 << 24
+    a = torch.zeros(n, device=DEV)
+    big = torch.randn(4096, 4096, device=DEV)
+    for it in range(5):
+        a.zero_()
+        for _ in range(20):                       # ~ms of queued work in front of the producer
+            big = big @ big
+            big = big / big.norm()
+        a.add_(float(it + 1))                     # producer on the compute stream
+        comm1.all_reduce_async(a, ocomm.SUM)      # must run after the add
+        comm1.wait()
+        b = a * 2.0                               # consumer on the compute stream: must run after the collective
+        torch.cuda.synchronize()
+        assert float(b.min()) == 2.0 * (it + 1) and float(b.max()) == 2.0 * (it + 1)
+
+
+def _small_model(seed=7):
+    from functools import partial
+    cfg = O.MAEConfig(input_size=64, in_chans=1, embed_dim=128, depth=2, num_heads=2, decoder_embed_dim=64, decoder_depth=2,
+                      decoder_num_heads=2, num_frames=12, t_patch_size=3, pred_t_dim=12, high_res_input_size=128)
+    P = O.init_params(cfg, seed=seed, bias_std=0.02)
+    m = models_mae.MaskedAutoencoderViT(
+        input_size=64, patch_size=16, in_chans=1, embed_dim=128, depth=2, num_heads=2, decoder_embed_dim=64, decoder_depth=2,
+        decoder_num_heads=2, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_frames=12, t_patch_size=3, sep_pos_embed=True,
+        cls_embed=True, pred_t_dim=12, high_res_input_size=128)
+    m.load_state_dict(P, strict=True)
+    return cfg, m.to(DEV)
+
+
+def test_reducer_one_rank_equals_local_gradient_and_isolates_cold_parameters(comm1):
+    cfg, m = _small_model()
+    m.train()
+    imgs = torch.rand(4, 1, 12, 64, 64, generator=torch.Generator().manual_seed(0)).to(DEV)
+    noise = torch.rand(4, cfg.num_patches, generator=torch.Generator().manual_seed(1)).to(DEV)
+    m.prepare()
+    # local gradient, no reducer (the weight-gradient GEMMs use fp32 atomics for split-K: compare with a tolerance)
+    loss, _, _ = m(imgs, mask_ratio=0.75, noise=noise)
+    loss.backward()
+    torch.cuda.synchronize()
+    local = m.arena.grad.clone()
+    m.arena.zero_grad()
+    red = FlatGradReducer(m, n_chunks=4, force=True, comm=comm1)
+    red.broadcast_parameters(0)
+    scaler = misc.NativeScalerWithGradNormCount(fp32=True, reducer=red)
+    opt = foptim.FusedAdamW(misc.add_weight_decay(m, 0.05), lr=0.0, betas=(0.9, 0.95))      # lr 0: the step leaves the weights alone
+    for step in range(3):
+        opt.zero_grad()
+        loss2, _, _ = m(imgs, mask_ratio=0.75, noise=noise)
+        scaler(loss2, opt, parameters=list(m.parameters()))
+        torch.cuda.synchronize()
+        assert float((m.arena.grad - local).abs().max()) <= 1e-5 * float(local.abs().max()) + 1e-7, step
+        if step == 0:
+            assert red._cold, "high_res_patch_embed never reports a gradient on 64x64 input"
+    names = {id(p): n for n, p in m.named_parameters()}
+    cold_names = sorted(names[k] for k in red._cold)
+    assert cold_names == ["high_res_patch_embed.proj.bias", "high_res_patch_embed.proj.weight"], cold_names
+    # after the first step the cold parameters sit in chunks of their own: only those are launched in finish()
+    cold_bytes = sum(4 * (e - s) for (s, e), c in zip(red.bounds, red.cold_chunk) if c)
+    hot_in_finish = [c for c in range(len(red.bounds)) if not red.cold_chunk[c] and red._remaining[c] > 0]
+    assert not hot_in_finish
+    assert 0 < cold_bytes < 4 * m.arena.total // 4
+    assert red.stats["launched_in_backward"] >= 2 * sum(1 for c in red.cold_chunk if not c)
+
+
+def test_reducer_skips_the_exchange_on_accumulation_micro_steps(comm1):
+    cfg, m = _small_model()
+    m.train()
+    m.prepare()
+    red = FlatGradReducer(m, n_chunks=4, force=True, comm=comm1)
+    scaler = misc.NativeScalerWithGradNormCount(fp32=True, reducer=red)
+    opt = foptim.FusedAdamW(misc.add_weight_decay(m, 0.05), lr=0.0, betas=(0.9, 0.95))
+    imgs = torch.rand(2, 1, 12, 64, 64, generator=torch.Generator().manual_seed(3)).to(DEV)
+    opt.zero_grad()
+    before = dict(red.stats)
+    loss, _, _ = m(imgs, mask_ratio=0.75)
+    assert scaler(loss / 2, opt, parameters=list(m.parameters()), update_grad=False) is None
+    assert red.stats == before
+    loss, _, _ = m(imgs, mask_ratio=0.75)
+    norm = scaler(loss / 2, opt, parameters=list(m.parameters()), update_grad=True)
+    torch.cuda.synchronize()
+    assert red.stats["bytes_total"] - before["bytes_total"] == 4 * m.arena.total
+    assert torch.isfinite(norm)
+
+
+@pytest.mark.skipif(_CHILD is None, reason="needs >= 2 GPUs on the box")
+def test_two_rank_gradients_equal_the_mean_of_the_local_ones():
+    out, _ = _CHILD.communicate(timeout=900)
+    assert _CHILD.returncode == 0, out.decode(errors="replace")[-4000:]
+    res = json.load(open(os.path.join(_CHILD_OUT, "result.json")))
+    assert res["world"] == 2 and res["backend"].startswith("octmae_comm")
+    assert res["params_equal_after_broadcast"]
+    assert res["max_rel_err"] <= 1e-5, res
+    assert res["ranks_agree"]
