@@ -87,6 +87,16 @@ int octmae_attn_bwd_dq(const void* qkv, const void* dout, const float* rowc, voi
 int octmae_attn_bwd_dkv(const void* qkv, const void* dout, const float* rowc, void* dqkv, int B, int N, int H, int HD, float scale,
                         void* stream);
 
+/* Fused backward (csrc/attn_bwd.hip): S, dP and exp once per score for all three gradients (5 matrix products and 1 exp per
+ * score instead of 7 and 2), dQ summed over key blocks in an fp32 workspace by one workgroup per (batch, head) in program
+ * order -- no atomics, bit-reproducible.  Same inputs and outputs as octmae_attn_bwd; `ws` is a device workspace of
+ * octmae_attn_bwd_fused_ws_kib(B, N, H, HD) KiB (dQ fp32 [B][H][N][HD] + the padded per-query constants), contents
+ * irrelevant on entry.  Three launches: per-query constants, full key blocks (512 keys at HD 32, 256 at HD 64), remaining keys
+ * + conversion of dQ to bf16. */
+int octmae_attn_bwd_fused_ws_kib(int B, int N, int H, int HD);
+int octmae_attn_bwd_fused(const void* qkv, const void* o, const void* dout, const float* lse, void* ws, void* dqkv, int B, int N,
+                          int H, int HD, float scale, void* stream);
+
 /* ---- random masking indices ---------------------------------------------------------------------
  * MaskedAutoencoderViT.random_masking index part, models_mae_joint_res_flash_attn.py:349-369:
  * ids_shuffle = argsort(noise) with ties -> lower index, ids_restore = its inverse, ids_keep = first len_keep,

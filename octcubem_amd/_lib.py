@@ -22,6 +22,8 @@ SIGNATURES = {
     "octmae_layernorm_bwd_ws_floats": [_i, _i],
     "octmae_attn_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "octmae_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "octmae_attn_bwd_fused_ws_kib": [_i, _i, _i, _i],
+    "octmae_attn_bwd_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "octmae_attn_bwd_rowconst": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "octmae_attn_bwd_dq_rowconst": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "octmae_attn_bwd_dq": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],

@@ -1,0 +1,975 @@
+// Fused (single-pass) attention backward for gfx950, head_dim 32 and 64, arbitrary sequence length.
+//
+// Backward of softmax((q k^T) scale) v  (Pre-training/custom_util/video_vit.py:130-134; flash path: flash-attn MHA built at
+// models_mae_joint_res_flash_attn.py:131-149) in ONE sweep over the scores: S, dP and exp are computed once per score and
+// feed all three gradients -- 5 matrix products and 1 exp per score, against 7 and 2 in the two-kernel form of attn.hip
+// (dQ kernel: S, dP, dQ; dK/dV kernel: S, dP, dV, dK).
+//
+// Work split (the guide's "key on the lane" structure, Appendix B 'Attention backward'):
+//   * one workgroup = 8 waves (two per SIMD) per (batch, head); it walks the sequence's KEY BLOCKS of KB = 8 waves x KW keys
+//     (512 keys at head_dim 32, 256 at 64) one after the other;
+//   * inside a key block each wave owns KW keys: its K and V fragments stay in registers, dK^T and dV^T of those keys
+//     accumulate in registers while the workgroup sweeps all 64-row query tiles (Q, dO and the two per-query constants arrive
+//     by LDS-DMA in a 3-deep ring);
+//   * S = Q K^T and dP = dO V^T are computed with the key on the MFMA lane (32x32x16), so P and dS are already the B operands
+//     of dV^T += dO^T P and dK^T += Q^T dS; only dS crosses LDS, once, as a [key][query] image of the whole key block;
+//   * dQ^T[d][q] += K^T[d][key] dS^T[key][q] is then taken over ALL keys of the block by 16x16x32 MFMAs -- every wave owns
+//     16x16 output tiles of the 64-query tile, its K^T fragments are loop invariants -- so no fp32 partial sums cross waves
+//     (head_dim 32 splits the keys in two halves: one 1-KiB exchange between two waves per tile);
+//   * dQ is summed over key blocks in an fp32 workspace by the SAME lane of the SAME workgroup (read-modify-write in program
+//     order): no atomics, bit-reproducible;
+//   * the keys past the last full block (N = 5121 and 1281 leave ONE: the cls token) go to a second, small kernel that splits
+//     the QUERY tiles over the waves instead, adds its share to the workspace, scales and writes dQ as bf16.
+// Numerics as in attn.hip: bf16 operands (P, dS rounded to bf16 for the MFMAs), fp32 accumulation, S in the exp2 domain
+// (K pre-multiplied by scale*log2e), row constants -lse*log2e and -delta as the initial accumulators.
+#include <type_traits>
+
+#include "attn_tile.hpp"
+#include "../../include/octmae.h"
+
+namespace octmae {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ f32x4_t mfma16(bf16x8 a, bf16x8 b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+#ifndef BWD_PIPE
+#define BWD_PIPE 0      // 0: plain unit loop (fastest measured); 2: three units in flight with sched_group_barrier interleave
+#endif
+#ifndef BWD_PRIO
+#define BWD_PRIO 0      // 1: static priority for waves 4-7 (swaps which half waits at the barrier; no net gain)
+#endif
+#ifndef BWD_P2_PRELOAD
+#define BWD_P2_PRELOAD 0
+#endif
+#ifndef BWD_KT_REGS
+#define BWD_KT_REGS 1   // K^T fragments of the dQ product in registers (plain form only: the pipelined form needs the registers)
+#endif
+#ifndef BWD_SB
+#define BWD_SB 1
+#endif
+#ifndef BWD_STAGGER
+#define BWD_STAGGER 0
+#endif
+
+#ifdef BWD_STAMP
+// diagnostic build only: per-wave cycle sums of the tile loop's segments (never read by the kernel itself)
+__device__ unsigned long long g_bwd_stamp[512 * 8 * 8];
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define STAMP(i)                                   \
+  do {                                             \
+    const unsigned long long now__ = stamp();      \
+    seg[i] += now__ - tlast;                       \
+    tlast = now__;                                 \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+
+template <int HD>
+struct BwdCfg {
+  static constexpr int NW = 8;                          // waves per workgroup
+  static constexpr int KW = (HD == 32) ? 64 : 32;       // keys per wave
+  static constexpr int NG = KW / 32;                    // 32-key groups per wave
+  static constexpr int KB = NW * KW;                    // keys per block
+  static constexpr int NB = 3;                          // Q / dO / constants ring depth (64-row tiles)
+  static constexpr int KS = HD / 16, DB = HD / 32;
+  static constexpr bool PAIR = (HD == 32);              // dQ keys split over a pair of waves
+  static constexpr int KH = PAIR ? KB / 2 : KB;         // keys one wave covers in the dQ product
+  static constexpr int QSTEPS = KH / 32;                // 16x16x32 k-steps per output tile
+  static constexpr int NT = PAIR ? 1 : 2;               // dQ output tiles a wave read-modify-writes per query tile
+  using T = Tile<HD>;
+  static constexpr int PD = 2 * T::BYTES / 1024 / NW;   // LDS-DMA data pieces per wave per tile (Q and dO together)
+  static_assert(PD >= 1 && PD * NW * 1024 == 2 * T::BYTES, "tile pieces must divide over the waves");
+  // LDS map
+  // (the rings come first: their fragment reads then reach everything from one base register through the 16-bit offset field)
+  static constexpr int QR = 0;                          // Q ring
+  static constexpr int OR_ = QR + NB * T::BYTES;        // dO ring
+  static constexpr int CR = OR_ + NB * T::BYTES;        // constants ring: [NB][2][64] f32
+  static constexpr int XCH = CR + NB * 512;             // pair exchange: [NW][64 lanes][4] f32
+  static constexpr int OLD = XCH + NW * 1024;           // workspace values of the tile in flight: [NW][NT][64 lanes][4] f32
+  static constexpr int IMG = OLD + NW * NT * 1024;      // dS image [KB keys][64 queries] bf16
+  static constexpr int IMG_BYTES = KB * 128;
+  static constexpr int KST = IMG + IMG_BYTES;           // this block's K rows [KB][HD] bf16 (swizzled 8-byte chunks), read
+  static constexpr int KST_BYTES = KB * HD * 2;         //   transposed as the A operand of the dQ product
+  static constexpr int LDS = KST + KST_BYTES;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  // 8-byte chunk c of K row `row`: conflict-free transposed reads of rows {0..3, 8..11} / {4..7, 12..15}
+  __device__ static __forceinline__ int kst_off(int row, int c) {
+    if (HD == 32) return row * 64 + ((c ^ (((row >> 3) & 1) << 2)) << 3);
+    const int sw = (row & 1) | (((row >> 2) & 1) << 1) | (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 3);
+    return row * 128 + ((c ^ sw) << 3);
+  }
+};
+
+// bit permutation of the low 4 row bits: conflict-free ds_write_b64 by 16 consecutive rows AND conflict-free transposed reads
+// of rows {0..3, 8..11} / {4..7, 12..15} (attention backward)
+__device__ __forceinline__ int img_sw(int row) {
+  return (row & 1) | (((row >> 2) & 1) << 1) | (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 3);
+}
+// byte offset of the 8-byte chunk c8 (4 queries) of key row `row` in the dS image (128-byte rows = 64 queries)
+__device__ __forceinline__ int img_off(int row, int c8) { return row * 128 + ((c8 ^ img_sw(row)) << 3); }
+
+// s_waitcnt vmcnt(CNT) -- the CNT youngest vector-memory operations of this wave stay in flight
+template <int CNT>
+__device__ __forceinline__ void wait_vm() {
+  static_assert(CNT >= 0 && CNT < 64, "vmcnt is 6 bits");
+  __builtin_amdgcn_s_waitcnt((CNT & 15) | ((CNT >> 4) << 14) | (7 << 4) | (15 << 8));
+}
+__device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }
+
+__device__ __forceinline__ void lds_dma16(unsigned m0v, unsigned voff, i32x4_t rsrc) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc) : "memory", "m0");
+#pragma clang diagnostic pop
+}
+__device__ __forceinline__ void lds_dma4(unsigned m0v, unsigned voff, i32x4_t rsrc) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc) : "memory", "m0");
+#pragma clang diagnostic pop
+}
+// The lane id made opaque at this point: LDS address arithmetic derived from the result cannot be hoisted out of the
+// enclosing loop (hoisted, the dozens of per-lane offsets of the unrolled tile body live across the whole kernel and spill).
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ i32x4_t make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  i32x4_t r = {(int)(unsigned)a, (int)(unsigned)(a >> 32), (int)bytes, 0x00020000};
+  r[0] = __builtin_amdgcn_readfirstlane(r[0]);
+  r[1] = __builtin_amdgcn_readfirstlane(r[1]);
+  r[2] = __builtin_amdgcn_readfirstlane(r[2]);
+  r[3] = __builtin_amdgcn_readfirstlane(r[3]);
+  return r;
+}
+
+// 8 bf16 A / B operand of a 32x32x16 or 16x16x32 MFMA from a PLAIN row-major [rows][rowb bytes] LDS array through two
+// transposed reads: element j = A[row0 + (j >> 2) * dr + (j & 3) ... ] -- see the call sites for the (row0, col0, dr) in use.
+//   lane 4q+p of each 16-lane group supplies row (row0 + q), columns col0 + 4p .. +3; lane i of the group receives column
+//   col0 + i of those 4 rows; the second read takes the rows `dr` further down.
+__device__ __forceinline__ bf16x8 tr_pair(const char* base, int rowb, int row0, int col0, int dr, int lane) {
+  const int q = (lane >> 2) & 3, p = lane & 3;
+  const char* a = base + (row0 + q) * rowb + (col0 + 4 * p) * 2;
+  return cat4(lds_tr_read(a), lds_tr_read(a + dr * rowb));
+}
+
+// =====================================================================================================
+// per-query constants, padded: rowc[0][bh][q] = -lse*log2e, rowc[1][bh][q] = -rowsum(dO * O); q in [N, NPAD): (-1e30, 0)
+// (a padded query row then gives P = exp2(-1e30) = 0 and dS = 0 whatever the zero-filled Q / dO rows produce)
+// =====================================================================================================
+template <int HD>
+__global__ __launch_bounds__(256) void attn_rowconst_pad_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                                const float* __restrict__ lse, float* __restrict__ rowc, int B,
+                                                                int N, int NPAD, int H) {
+  const size_t plane = (size_t)B * H * NPAD;
+  constexpr int LPH = HD / 8;  // lanes per head
+  const int lane = threadIdx.x & 63;
+  const int nwaves = gridDim.x * 4;
+  const int D = H * HD, nchunk = D / 8;
+  const int rows = B * NPAD;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nwaves) {
+    const int b = row / NPAD, q = row % NPAD;
+    for (int c0 = 0; c0 < nchunk; c0 += 64) {
+      const int c = c0 + lane;
+      float s = 0.f;
+      if (c < nchunk && q < N) {
+        const size_t src = ((size_t)b * N + q) * D + 8 * c;
+        const u32x4 a = *reinterpret_cast<const u32x4*>(o + src);
+        const u32x4 d = *reinterpret_cast<const u32x4*>(dout + src);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += bflo(a[e]) * bflo(d[e]) + bfhi(a[e]) * bfhi(d[e]);
+      }
+#pragma unroll
+      for (int m = 1; m < LPH; m <<= 1) s += __shfl_xor(s, m, 64);
+      if (c < nchunk && (lane % LPH) == 0) {
+        const int head = c / LPH;
+        const size_t i = ((size_t)b * H + head) * NPAD + q;
+        rowc[i] = (q < N) ? -lse[((size_t)b * H + head) * N + q] * LOG2E : -1.0e30f;
+        rowc[plane + i] = -s;
+      }
+    }
+  }
+}
+
+// =====================================================================================================
+// main kernel: the full key blocks
+// =====================================================================================================
+template <int HD>
+__global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                               const float* __restrict__ rowc, float* __restrict__ dq_ws,
+                                                               bf16_t* __restrict__ dqkv, int N, int NPAD, int H, int nkb,
+                                                               float scale) {
+  using C = BwdCfg<HD>;
+  using T = typename C::T;
+  constexpr int KS = C::KS, DB = C::DB, NG = C::NG, NB = C::NB, PD = C::PD, NT = C::NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  // (batch, head) pair.  Consecutive block ids go to the 8 XCDs round robin; xcd_remap hands every XCD a CONTIGUOUS range of
+  // pairs instead, i.e. all 16 heads of a sample: their Q / dO rows are adjacent 64- or 128-byte pieces of the same lines,
+  // fetched once per XCD L2 instead of once per head.
+  const int bh = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int b = bh / H, head = bh % H;
+  const size_t rs = (size_t)3 * H * HD, os = (size_t)H * HD;
+  const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)head * HD;
+  const bf16_t* kb_ = qb + (size_t)H * HD;
+  const bf16_t* vb_ = qb + (size_t)2 * H * HD;
+  const bf16_t* dob = dout + (size_t)b * N * os + (size_t)head * HD;
+  const float sc2 = scale * LOG2E;
+  const int ntiles = (N + 63) / 64;
+
+  // ---- LDS-DMA plan of this wave: PD data pieces (Q pieces first, then dO pieces) + one constants row per tile
+  const i32x4_t rsQ = make_rsrc(qb, (unsigned)(((size_t)(N - 1) * rs + HD) * 2));
+  const i32x4_t rsO = make_rsrc(dob, (unsigned)(((size_t)(N - 1) * os + HD) * 2));
+  constexpr int PIECES = T::BYTES / 1024;
+  unsigned dvoff[PD], dlds[PD], dstride[PD];
+  bool disq[PD];
+#pragma unroll
+  for (int i = 0; i < PD; ++i) {
+    const int gp = wid * PD + i;
+    const bool isq = gp < PIECES;                // wave-uniform
+    const int piece = isq ? gp : gp - PIECES;
+    const int q = piece * 64 + lane;
+    const int row = q / T::CHUNKS, c = (q % T::CHUNKS) ^ T::sw(row);
+    const size_t stride = isq ? rs : os;
+    dvoff[i] = (unsigned)(((size_t)row * stride + c * 8) * 2);
+    dstride[i] = (unsigned)(64 * stride * 2);
+    dlds[i] = (unsigned)((isq ? C::QR : C::OR_) + piece * 1024);
+    disq[i] = isq;
+  }
+  const i32x4_t rsC = make_rsrc(rowc + (size_t)(wid & 1) * gridDim.x * NPAD + (size_t)bh * NPAD, (unsigned)((size_t)NPAD * 4));
+  auto issue = [&](int tt) {
+    const int slot = tt % NB;
+#pragma unroll
+    for (int i = 0; i < PD; ++i) {
+      const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + dlds[i] + (unsigned)(slot * T::BYTES)));
+      lds_dma16(m0v, dvoff[i] + (unsigned)tt * dstride[i], disq[i] ? rsQ : rsO);
+    }
+    const unsigned m0c = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + C::CR + slot * 512 + (wid & 1) * 256));
+    lds_dma4(m0c, (unsigned)((tt * 64 + lane) * 4), rsC);
+  };
+
+  // ---- dQ workspace of this (batch, head): fp32 [N][HD]; rows >= N fall outside the descriptor (loads 0, stores dropped)
+  float* wsb = dq_ws + (size_t)bh * N * HD;
+  const i32x4_t rsW = make_rsrc(wsb, (unsigned)((size_t)N * HD * 4));            // for the LDS-DMA loads (inline asm)
+  const __amdgpu_buffer_rsrc_t rsWs = __builtin_amdgcn_make_buffer_rsrc(           // the same range for the builtin stores
+      reinterpret_cast<void*>(((unsigned long long)(unsigned)rsW[1] << 32) | (unsigned)rsW[0]), 0, rsW[2], 0x00020000);
+  // this wave's dQ^T output tiles: rows d = 16 dt + 4 (lane >> 4) + e, columns q = 16 qt + (lane & 15)
+  const int dt = C::PAIR ? ((wid >> 1) & 1) : (wid & 3);
+  const int qpair = wid >> 2;
+  const int khalf = C::PAIR ? (wid & 1) : 0;
+  const int own = C::PAIR ? khalf : 0;            // PAIR: the tile (of its two) this wave keeps and read-modify-writes
+  const int c16 = lane & 15, kg = lane >> 4;
+  unsigned wsoff[NT];                             // byte offset within tile 0's rows
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int qt = 2 * qpair + (C::PAIR ? own : i);
+    wsoff[i] = (unsigned)(((16 * qt + c16) * HD + 16 * dt + 4 * kg) * 4);
+  }
+  const unsigned ws_tile = (unsigned)(64 * HD * 4);
+
+  // ---- LDS addressing: a few per-lane BASES + compile-time XOR masks + immediates.  The swizzles are XORs on chunk-index
+  // bits that the fragment index (k-step s, head-dim block d, sub-tile u) also occupies, so "address of fragment (u, s, d)" is
+  // base ^ mask(s, d) + constant(u, slot): one v_xor per read instead of the full index arithmetic (which, recomputed per
+  // use, made 2/3 of this kernel's VALU instructions integer work; hoisted by the compiler instead, it lived in ~60 VGPRs
+  // across the whole kernel and spilled).
+  //   row fragment (Tile::row_frag): row r, chunk (2s + h) ^ sw(r)            = rowb ^ (s << 5)          + 32u rows
+  //   transposed fragment (Tile::tr_frag): rows 16s + 4h + q (+8), chunk ((db>>3) + 2gi + (p>>1)) ^ sw(row)
+  //                                                                            = trb ^ (d << 6) [^ 32] + 16s rows (+8 rows)
+  //   dS image write: row krow, 8-byte chunk (8u + 4s + 2j + h) ^ img_sw(r)   = imgb ^ ((8u + 4s + 2j) << 3)
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3;
+#if BWD_PIPE != 0
+  const int gi = (lane >> 4) & 1;
+#endif
+#if BWD_PIPE != 0
+  const int rowb = r * T::ROWB + ((h ^ T::sw(r)) << 4);
+  const int trb = (4 * h + q4) * T::ROWB + (((2 * gi + (p4 >> 1)) ^ T::sw(4 * h + q4)) << 4) + (p4 & 1) * 8;
+  const int imgb = C::IMG + (wid * C::KW + r) * 128 + ((h ^ img_sw(r)) << 3);
+  const int cstb = 16 * h;
+#endif
+  // phase 2 (dQ product): dS image rows 32 ks + 8 kg + q4 (+4), chunk (4 qt + p) ^ img_sw(row); staged K rows likewise
+  const int p2row = khalf * C::KH + 8 * kg + q4;
+  const int p2a0 = C::IMG + p2row * 128 + (((8 * qpair + p4) ^ img_sw((8 * kg + q4) & 15)) << 3);
+  const int p2a1 = C::IMG + (p2row + 4) * 128 + (((8 * qpair + p4) ^ img_sw((8 * kg + q4 + 4) & 15)) << 3);
+  const int p2k0 = C::KST + C::kst_off(p2row, 4 * dt + p4);
+  const int p2k1 = C::KST + C::kst_off(p2row + 4, 4 * dt + p4);
+
+#if BWD_PRIO
+  // waves 4-7 are the SIMD partners of waves 0-3 and, being younger, lose every arbitration for the vector and matrix issue
+  // ports: in-kernel stamps had them finish a tile's units 30 % after waves 0-3, which then idle at the barrier.  One static
+  // priority raise (MI355X_MICROARCH.md, "Two waves per SIMD", item 4); no per-segment flips.
+  if (wid >= 4) __builtin_amdgcn_s_setprio(BWD_PRIO);
+#endif
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int key0 = kb * C::KB;
+    // ---- stage this block's K rows in LDS for the transposed reads of the dQ product (A operand K^T)
+    {
+      constexpr int CH = HD / 8;                 // 16-byte chunks per row
+      constexpr int TOTAL = C::KB * CH;
+#pragma unroll
+      for (int i = 0; i < TOTAL / 512; ++i) {
+        const int c = tid + 512 * i;
+        const int row = c / CH, cc = c % CH;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(kb_ + (size_t)(key0 + row) * rs + 8 * cc);
+        *reinterpret_cast<u32x2*>(smem + C::KST + C::kst_off(row, 2 * cc)) = u32x2{v[0], v[1]};
+        *reinterpret_cast<u32x2*>(smem + C::KST + C::kst_off(row, 2 * cc + 1)) = u32x2{v[2], v[3]};
+      }
+    }
+    // ---- this wave's keys: B operands of S (pre-scaled) and dP
+    bf16x8 kS[NG][KS], vS[NG][KS];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const size_t krow = (size_t)(key0 + wid * C::KW + 32 * g + r) * rs;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const u32x4 kv = *reinterpret_cast<const u32x4*>(kb_ + krow + 16 * s + 8 * h);
+        const u32x4 vv = *reinterpret_cast<const u32x4*>(vb_ + krow + 16 * s + 8 * h);
+        kS[g][s] = scale_frag(kv, sc2);
+        vS[g][s] = __builtin_bit_cast(bf16x8, vv);
+      }
+    }
+    f32x16 dk[NG][DB], dv[NG][DB];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[g][d][e] = 0.f; dv[g][d][e] = 0.f; }
+    __syncthreads();                              // K staging visible
+#if BWD_KT_REGS
+    bf16x8 kTr[C::QSTEPS];                        // loop-invariant A operands of the dQ product, read once per key block
+#pragma unroll
+    for (int ks = 0; ks < C::QSTEPS; ++ks)
+      kTr[ks] = cat4(lds_tr_read(smem + p2k0 + ks * 32 * HD * 2), lds_tr_read(smem + p2k1 + ks * 32 * HD * 2));
+#endif
+
+    // ---- ring prologue
+    issue(0);
+    issue(1);
+    wait_vm<PD + 1>();                            // tile 0 landed
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();
+
+    f32x4_t acc0, acc1;                           // dQ^T partial tiles (qt = 2 qpair, 2 qpair + 1)
+    acc0 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    acc1 = acc0;
+    const char* myold = smem + C::OLD + wid * NT * 1024 + lane * 16;
+
+    // finish(tp): tile tp's dQ^T -> workspace.  Its partial sums are in acc0/acc1 (and, PAIR, in the partner's exchange
+    // slot); the workspace values were requested at the start of tile tp by LDS-DMA into this wave's OLD slot (a register
+    // load would make the compiler drain the whole DMA ring at its first use).
+    auto finish = [&](int tp) {
+      wait_vm<PD + 1>();                          // everything older than tile tp+2's PD+1 DMAs has landed: OLD(tp) included
+      if (C::PAIR) {
+        const f32x4_t other = *reinterpret_cast<const f32x4_t*>(smem + C::XCH + (wid ^ 1) * 1024 + lane * 16);
+        f32x4_t v = (own ? acc1 : acc0) + other;
+        if (kb > 0) v += *reinterpret_cast<const f32x4_t*>(myold);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsWs, wsoff[0] + (unsigned)tp * ws_tile, 0, 0);
+      } else {
+        f32x4_t v0 = acc0, v1 = acc1;
+        if (kb > 0) {
+          v0 += *reinterpret_cast<const f32x4_t*>(myold);
+          v1 += *reinterpret_cast<const f32x4_t*>(myold + (NT - 1) * 1024);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), rsWs, wsoff[0] + (unsigned)tp * ws_tile, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), rsWs, wsoff[NT - 1] + (unsigned)tp * ws_tile, 0, 0);
+      }
+      wait_lgkm0();                               // the OLD / exchange reads have returned before anything rewrites them
+    };
+
+#ifdef BWD_STAMP
+    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = stamp();
+#endif
+    for (int t = 0; t < ntiles; ++t) {
+      // ---- phase 1: previous tile's dQ out, this tile's requests, S / dP / P / dS, dS -> image, dV / dK
+      if (t > 0) finish(t - 1);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const unsigned m0o = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + C::OLD + (wid * NT + i) * 1024));
+        lds_dma16(m0o, wsoff[i] + (unsigned)t * ws_tile, rsW);
+      }
+      issue(t + 2);
+      STAMP(0);
+      // this tile's bases (opaque: whatever is derived from them stays inside the tile loop, in a handful of registers)
+      const int slot = t % NB;
+      const int slotq = C::QR + slot * T::BYTES;          // scalar
+#if BWD_PIPE == 0
+      // Plain form: per 32-query sub-tile the row constants and the Q / dO fragments are read ONCE and shared by the wave's
+      // key groups (least LDS traffic and fewest instructions; no explicit software pipeline -- the partner wave and the
+      // compiler's own scheduling provide the overlap).
+#pragma unroll 1
+      for (int u = 0; u < 2; ++u) {
+        f32x16 lse_t, dlt_t;                      // row constants: register 4G+e <-> query row 32u + 8G + 4h + e
+        const float* cC = reinterpret_cast<const float*>(smem + C::CR + slot * 512);
+        const char* cQ = smem + slotq;
+        const char* cO = cQ + (C::OR_ - C::QR);
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(cC + 32 * u + 8 * G + 4 * h);
+          const f32x4 d = *reinterpret_cast<const f32x4*>(cC + 64 + 32 * u + 8 * G + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { lse_t[4 * G + e] = a[e]; dlt_t[4 * G + e] = d[e]; }
+        }
+        bf16x8 qrow[KS], orow[KS], qT2[2][DB], oT2[2][DB];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          qrow[s] = T::row_frag(cQ, 32 * u, s, lane);
+          orow[s] = T::row_frag(cO, 32 * u, s, lane);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int d = 0; d < DB; ++d) {
+            qT2[s][d] = T::tr_frag(cQ, 32 * u, s, 32 * d, lane);
+            oT2[s][d] = T::tr_frag(cO, 32 * u, s, 32 * d, lane);
+          }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          f32x16 sa = mfma32(qrow[0], kS[g][0], lse_t);
+#pragma unroll
+          for (int s = 1; s < KS; ++s) sa = mfma32(qrow[s], kS[g][s], sa);
+          f32x16 dp = mfma32(orow[0], vS[g][0], dlt_t);
+#pragma unroll
+          for (int s = 1; s < KS; ++s) dp = mfma32(orow[s], vS[g][s], dp);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float p = fast_exp2(sa[e]);
+            sa[e] = p;
+            dp[e] = p * dp[e];                    // dS / scale
+          }
+          const int krow = wid * C::KW + 32 * g + r;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const bf16x8 pf = acc_to_frag(sa, s);
+            const bf16x8 dsf = acc_to_frag(dp, s);
+            const u32x4 w = __builtin_bit_cast(u32x4, dsf);
+            *reinterpret_cast<u32x2*>(smem + C::IMG + img_off(krow, 8 * u + 4 * s + h)) = u32x2{w[0], w[1]};
+            *reinterpret_cast<u32x2*>(smem + C::IMG + img_off(krow, 8 * u + 4 * s + 2 + h)) = u32x2{w[2], w[3]};
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+              dv[g][d] = mfma32(oT2[s][d], pf, dv[g][d]);
+              dk[g][d] = mfma32(qT2[s][d], dsf, dk[g][d]);
+            }
+          }
+        }
+      }
+#else
+      // Units (32 queries x 32 keys of this wave) are software-pipelined by hand, the order pinned with sched_barrier:
+      //   R  LDS reads of unit n+1's operands (row constants straight into its accumulators, Q / dO row fragments) and of
+      //      unit n's transposed Q / dO fragments            -- their latency passes under V1
+      //   V1 exp2 and the dS product of unit n
+      //   M1 S and dP MFMAs of unit n+1                       -- execute under V2
+      //   V2 bf16 packing of P and dS of unit n, dS -> image
+      //   M2 dV^T and dK^T MFMAs of unit n                    -- execute under the next R / V1
+      // Exposed LDS latency was what serialised the unpipelined form (in-kernel stamps: a wave spent ~1200 cycles per unit,
+      // four times its issue work).
+      constexpr int NU = 2 * NG;
+      auto loadA = [&](auto n_, f32x16& sa, f32x16& dp, bf16x8 (&qf)[KS], bf16x8 (&of)[KS]) {
+        constexpr int n = decltype(n_)::value, u = n / NG;
+        const char* cCb = smem + C::CR + slot * 512 + opaque(cstb);
+        const int rowt = opaque(rowb) + slotq;
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {             // row constants as the initial accumulators: register 4G+e <-> query 32u + 8G + 4h + e
+          const f32x4 a = *reinterpret_cast<const f32x4*>(cCb + (32 * u + 8 * G) * 4);
+          const f32x4 d = *reinterpret_cast<const f32x4*>(cCb + (64 + 32 * u + 8 * G) * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sa[4 * G + e] = a[e]; dp[4 * G + e] = d[e]; }
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const char* a = smem + ((rowt ^ (s << 5)) + 32 * u * T::ROWB);
+          qf[s] = *reinterpret_cast<const bf16x8*>(a);
+          of[s] = *reinterpret_cast<const bf16x8*>(a + (C::OR_ - C::QR));
+        }
+      };
+      auto loadC = [&](auto n_, bf16x8 (&oT)[2][DB], bf16x8 (&qT)[2][DB]) {
+        constexpr int n = decltype(n_)::value, u = n / NG;
+        const int trt = opaque(trb) + slotq;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          const char* lo = smem + ((trt ^ (d << 6)) + 32 * u * T::ROWB);            // rows 16s + 4h + q
+          const char* hi = smem + ((trt ^ (d << 6) ^ 32) + (32 * u + 8) * T::ROWB);  // rows 16s + 8 + 4h + q: sw differs in bit 1
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            qT[s][d] = cat4(lds_tr_read(lo + 16 * s * T::ROWB), lds_tr_read(hi + 16 * s * T::ROWB));
+            oT[s][d] = cat4(lds_tr_read(lo + 16 * s * T::ROWB + (C::OR_ - C::QR)), lds_tr_read(hi + 16 * s * T::ROWB + (C::OR_ - C::QR)));
+          }
+        }
+      };
+      auto mmaA = [&](auto n_, f32x16& sa, f32x16& dp, const bf16x8 (&qf)[KS], const bf16x8 (&of)[KS]) {
+        constexpr int n = decltype(n_)::value, g = n % NG;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) sa = mfma32(qf[s], kS[g][s], sa);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) dp = mfma32(of[s], vS[g][s], dp);
+      };
+      auto expmul = [&](f32x16& sa, f32x16& dp) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float p = fast_exp2(sa[e]);
+          sa[e] = p;
+          dp[e] = p * dp[e];                      // dS / scale
+        }
+      };
+      auto pack = [&](auto n_, const f32x16& sa, const f32x16& dp, bf16x8 (&pf)[2], bf16x8 (&dsf)[2]) {
+        constexpr int n = decltype(n_)::value, u = n / NG, g = n % NG;
+        const int imgt = opaque(imgb);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          pf[s] = acc_to_frag(sa, s);
+          dsf[s] = acc_to_frag(dp, s);
+          const u32x4 w = __builtin_bit_cast(u32x4, dsf[s]);
+          // registers 8s..8s+3 <-> queries 32u + 16s + 4h + 0..3 ; 8s+4..8s+7 <-> 32u + 16s + 8 + 4h + 0..3
+          *reinterpret_cast<u32x2*>(smem + ((imgt ^ ((8 * u + 4 * s) << 3)) + 32 * g * 128)) = u32x2{w[0], w[1]};
+          *reinterpret_cast<u32x2*>(smem + ((imgt ^ ((8 * u + 4 * s + 2) << 3)) + 32 * g * 128)) = u32x2{w[2], w[3]};
+        }
+      };
+      auto mmaC = [&](auto n_, const bf16x8 (&pf)[2], const bf16x8 (&dsf)[2], const bf16x8 (&oT)[2][DB], const bf16x8 (&qT)[2][DB]) {
+        constexpr int n = decltype(n_)::value, g = n % NG;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int d = 0; d < DB; ++d) {
+            dv[g][d] = mfma32(oT[s][d], pf[s], dv[g][d]);
+            dk[g][d] = mfma32(qT[s][d], dsf[s], dk[g][d]);
+          }
+      };
+      {
+        f32x16 sX, pX, sY, pY;
+        bf16x8 qf[KS], of[KS], oT[2][DB], qT[2][DB], pf[2], dsf[2];
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define IC(n) std::integral_constant<int, n>{}
+#if BWD_STAGGER > 0
+        if (wid >= 4) __builtin_amdgcn_s_sleep(BWD_STAGGER);
+#endif
+#if BWD_PIPE != 0
+        // Three units in flight.  Every region pairs MFMAs with INDEPENDENT vector work of another unit, interleaved by
+        // sched_group_barrier, so that one wave overlaps the two pipes by itself (its SIMD partner runs the same code at
+        // about the same place and competes for the same pipe at the same time):
+        //   Y_k: S / dP MFMAs of unit k+1  ||  bf16 packing of P, dS of unit k + dS -> image      (+ transposed reads for X_k)
+        //   X_k: dV^T / dK^T MFMAs of unit k  ||  exp2 and dS product of unit k+1                  (+ operand reads of unit k+2)
+#define MFMA_VALU(nm, nv, rep)                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < rep; ++i_) {                          \
+          __builtin_amdgcn_sched_group_barrier(0x008, nm, 0);                          \
+          __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);                          \
+        }
+#define MFMA_TRANS_VALU(nm, nt, nv, rep)                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < rep; ++i_) {                          \
+          __builtin_amdgcn_sched_group_barrier(0x008, nm, 0);                          \
+          __builtin_amdgcn_sched_group_barrier(0x400, nt, 0);                          \
+          __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);                          \
+        }
+        constexpr int NM = 2 * KS;                       // MFMAs per region
+        loadA(IC(0), sX, pX, qf, of); SB();
+        mmaA(IC(0), sX, pX, qf, of); SB();
+        loadA(IC(1), sY, pY, qf, of); SB();
+        expmul(sX, pX); SB();
+#define STEP(k, SK, PK, SN, PN, HASN1, HASN2)                                          \
+        loadC(IC(k), oT, qT); SB();                                                    \
+        if constexpr (HASN1) mmaA(IC(k + 1), SN, PN, qf, of);                          \
+        pack(IC(k), SK, PK, pf, dsf);                                                  \
+        if constexpr (HASN1) { MFMA_VALU(1, 16 / NM + 1, NM) }                         \
+        SB();                                                                          \
+        if constexpr (HASN2) loadA(IC(k + 2), SK, PK, qf, of);                         \
+        SB();                                                                          \
+        mmaC(IC(k), pf, dsf, oT, qT);                                                  \
+        if constexpr (HASN1) expmul(SN, PN);                                           \
+        if constexpr (HASN1) { MFMA_TRANS_VALU(1, 16 / NM, 8 / NM, NM) }               \
+        SB();
+        if constexpr (NU == 2) {
+          STEP(0, sX, pX, sY, pY, true, false)
+          STEP(1, sY, pY, sX, pX, false, false)
+        } else {
+          STEP(0, sX, pX, sY, pY, true, true)
+          STEP(1, sY, pY, sX, pX, true, true)
+          STEP(2, sX, pX, sY, pY, true, false)
+          STEP(3, sY, pY, sX, pX, false, false)
+        }
+#undef STEP
+#undef MFMA_VALU
+#undef MFMA_TRANS_VALU
+#endif
+#undef SB
+#undef IC
+      }
+#endif
+      STAMP(1);
+      wait_lgkm0();
+      __builtin_amdgcn_s_barrier();               // A: the image of tile t is complete
+      STAMP(2);
+      // ---- phase 2: dQ^T tiles of this wave over its KH keys
+      acc0 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      acc1 = acc0;
+      {
+        // B operand dS^T[k = key][col q] of the two output tiles (qt = 2 qpair, 2 qpair + 1: chunk bit 2) and the A operand
+        // K^T[row d = 16 dt + c16][k = key 32 ks + 8 kg + j] from the staged K rows, all by transposed reads
+        const char* a00 = smem + opaque(p2a0);
+        const char* a01 = smem + opaque(p2a1);
+        const char* a10 = smem + (opaque(p2a0) ^ 32);
+        const char* a11 = smem + (opaque(p2a1) ^ 32);
+#if !BWD_KT_REGS
+        const char* k0 = smem + opaque(p2k0);
+        const char* k1 = smem + opaque(p2k1);
+#endif
+#if BWD_P2_PRELOAD
+        // every operand first (the unit pipeline's registers are free here), then the MFMAs back to back: with the reads
+        // issued a k-step or two ahead, as the compiler orders them, this phase took 900-1400 cycles for 256 cycles of MFMAs
+        bf16x8 ka[C::QSTEPS], b0[C::QSTEPS], b1[C::QSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < C::QSTEPS; ++ks) {
+          ka[ks] = cat4(lds_tr_read(k0 + ks * 32 * HD * 2), lds_tr_read(k1 + ks * 32 * HD * 2));
+          b0[ks] = cat4(lds_tr_read(a00 + ks * 32 * 128), lds_tr_read(a01 + ks * 32 * 128));
+          b1[ks] = cat4(lds_tr_read(a10 + ks * 32 * 128), lds_tr_read(a11 + ks * 32 * 128));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < C::QSTEPS; ++ks) {
+          acc0 = mfma16(ka[ks], b0[ks], acc0);
+          acc1 = mfma16(ka[ks], b1[ks], acc1);
+        }
+#else
+#pragma unroll
+        for (int ks = 0; ks < C::QSTEPS; ++ks) {
+#if BWD_KT_REGS
+          const bf16x8 ka = kTr[ks];
+#else
+          const bf16x8 ka = cat4(lds_tr_read(k0 + ks * 32 * HD * 2), lds_tr_read(k1 + ks * 32 * HD * 2));
+#endif
+          const bf16x8 b0 = cat4(lds_tr_read(a00 + ks * 32 * 128), lds_tr_read(a01 + ks * 32 * 128));
+          const bf16x8 b1 = cat4(lds_tr_read(a10 + ks * 32 * 128), lds_tr_read(a11 + ks * 32 * 128));
+          acc0 = mfma16(ka, b0, acc0);
+          acc1 = mfma16(ka, b1, acc1);
+        }
+#endif
+      }
+      if (C::PAIR)                                 // hand the tile this wave does not keep to its partner
+        *reinterpret_cast<f32x4_t*>(smem + C::XCH + wid * 1024 + lane * 16) = own ? acc0 : acc1;
+      STAMP(3);
+      if (t == 0) wait_vm<NT + PD + 1>();         // tile t+1 landed (younger: this tile's NT loads, tile t+2's DMAs ...
+      else wait_vm<2 * NT + PD + 1>();            //  ... and, from the second tile on, the NT stores of finish(t-1))
+      wait_lgkm0();
+      STAMP(4);
+      __builtin_amdgcn_s_barrier();               // B: image and ring slot free, exchange slots visible
+      STAMP(5);
+    }
+#ifdef BWD_STAMP
+    if (kb == 0 && lane == 0 && blockIdx.x < 512)
+      for (int i = 0; i < 6; ++i) g_bwd_stamp[(blockIdx.x * 8 + wid) * 8 + i] = seg[i];
+#endif
+    finish(ntiles - 1);
+    // ---- dK, dV of this wave's keys
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      bf16_t* drow = dqkv + ((size_t)b * N + key0 + wid * C::KW + 32 * g + r) * rs + (size_t)head * HD;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+          const u32x2 wk = {pack2bf(dk[g][d][4 * G] * scale, dk[g][d][4 * G + 1] * scale),
+                            pack2bf(dk[g][d][4 * G + 2] * scale, dk[g][d][4 * G + 3] * scale)};
+          const u32x2 wv = {pack2bf(dv[g][d][4 * G], dv[g][d][4 * G + 1]), pack2bf(dv[g][d][4 * G + 2], dv[g][d][4 * G + 3])};
+          *reinterpret_cast<u32x2*>(drow + (size_t)H * HD + d * 32 + 8 * G + 4 * h) = wk;
+          *reinterpret_cast<u32x2*>(drow + (size_t)2 * H * HD + d * 32 + 8 * G + 4 * h) = wv;
+        }
+    }
+    // the next block's workspace read-modify-write of a row is done by the same lane as this block's: program order;
+    // drain everything (stale DMA of tiles past the end included) before the K staging reuses the image region
+    wait_vm<0>();
+    __syncthreads();
+  }
+}
+
+// =====================================================================================================
+// tail kernel: the keys past the last full block (query tiles split over the waves), then dQ workspace -> bf16
+// =====================================================================================================
+template <int HD>
+__global__ __launch_bounds__(512, 2) void attn_bwd_tail_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                              const float* __restrict__ rowc, float* __restrict__ dq_ws,
+                                                              bf16_t* __restrict__ dqkv, int N, int NPAD, int H, int key_start,
+                                                              float scale) {
+  constexpr int KS = HD / 16, DB = HD / 32, ROWB = HD * 2;
+  constexpr int NW = 8;
+  // LDS: K group [32][HD] | V group [32][HD] | per wave: Q sub-tile [32][HD], dO sub-tile [32][HD], dS image [32 keys][32 q]
+  //      | reduction scratch [NW][64][16] f32
+  constexpr int KG = 0, VG = KG + 32 * ROWB, WV = VG + 32 * ROWB, PERW = 2 * 32 * ROWB + 32 * 64, RED = WV + NW * PERW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5, gi = (lane >> 4) & 1;
+  const int bh = blockIdx.x;
+  const int b = bh / H, head = bh % H;
+  const size_t rs = (size_t)3 * H * HD, os = (size_t)H * HD;
+  const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)head * HD;
+  const bf16_t* kb_ = qb + (size_t)H * HD;
+  const bf16_t* vb_ = qb + (size_t)2 * H * HD;
+  const bf16_t* dob = dout + (size_t)b * N * os + (size_t)head * HD;
+  const float* rc_l = rowc + (size_t)bh * NPAD;
+  const float* rc_d = rowc + (size_t)gridDim.x * NPAD + (size_t)bh * NPAD;
+  float* wsb = dq_ws + (size_t)bh * N * HD;
+  const float sc2 = scale * LOG2E;
+  const int nsub = (N + 31) / 32;
+  const int ngroups = (N - key_start + 31) / 32;          // 0: nothing but the conversion
+  char* myQ = smem + WV + wid * PERW;
+  char* myO = myQ + 32 * ROWB;
+  char* myS = myO + 32 * ROWB;
+
+  // dQ rows of this lane for sub-tile j: query 32 j + r, head-dim runs 32 db + 8 G + 4 h .. + 3
+  auto convert_only = [&]() {
+    for (int j = wid; j < nsub; j += NW) {
+      const int q = 32 * j + r;
+      if (q >= N) continue;
+      bf16_t* drow = dqkv + ((size_t)b * N + q) * rs + (size_t)head * HD;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(wsb + (size_t)q * HD + 32 * d + 8 * G + 4 * h);
+          *reinterpret_cast<u32x2*>(drow + 32 * d + 8 * G + 4 * h) =
+              u32x2{pack2bf(v[0] * scale, v[1] * scale), pack2bf(v[2] * scale, v[3] * scale)};
+        }
+    }
+  };
+  if (ngroups == 0) {
+    convert_only();
+    return;
+  }
+
+  for (int gk = 0; gk < ngroups; ++gk) {
+    const int key0 = key_start + 32 * gk;
+    const bool last = (gk == ngroups - 1);
+    const bool have_ws = (key_start > 0) || (gk > 0);     // the workspace already holds a partial sum
+    // ---- stage the K and V rows of this group (rows >= N: zeros)
+    {
+      constexpr int CH = HD / 8;
+      for (int c = tid; c < 2 * 32 * CH; c += 512) {
+        const int which = c / (32 * CH), cc = c % (32 * CH);
+        const int row = cc / CH, col = cc % CH;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (key0 + row < N) v = *reinterpret_cast<const u32x4*>((which ? vb_ : kb_) + (size_t)(key0 + row) * rs + 8 * col);
+        *reinterpret_cast<u32x4*>(smem + (which ? VG : KG) + row * ROWB + col * 16) = v;
+      }
+    }
+    __syncthreads();
+    bf16x8 kS[KS], vS[KS], kT[2][DB];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      kS[s] = scale_frag(*reinterpret_cast<const u32x4*>(smem + KG + r * ROWB + (16 * s + 8 * h) * 2), sc2);
+      vS[s] = *reinterpret_cast<const bf16x8*>(smem + VG + r * ROWB + (16 * s + 8 * h) * 2);
+    }
+    // A operand of dQ^T[d][q] = K^T dS^T (32x32x16, natural k order): A[row d = 32 db + r][k = key 16 s + 8 h + j]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int d = 0; d < DB; ++d) kT[s][d] = tr_pair(smem + KG, ROWB, 16 * s + 8 * h, 32 * d + 16 * gi, 4, lane);
+    const bool key_live = (key0 + r) < N;
+    f32x16 dk[DB], dv[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { dk[d][e] = 0.f; dv[d][e] = 0.f; }
+
+    // The sub-tile after the current one is requested (Q, dO rows and the row constants, into registers) before the current
+    // one is computed: a wave walks ~N/256 sub-tiles back to back and nothing else hides the global-load latency
+    // (without the prefetch this kernel took 330 us for ONE key at B = 32, N = 5121).
+    constexpr int CHT = HD / 8, NCH = 32 * CHT / 64;
+    u32x4 nq[NCH], no[NCH];
+    f32x4 na[4], nd[4];
+    auto prefetch = [&](int j) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        const int row = c / CHT, col = c % CHT;
+        nq[i] = u32x4{0u, 0u, 0u, 0u};
+        no[i] = nq[i];
+        if (j < nsub && 32 * j + row < N) {
+          nq[i] = *reinterpret_cast<const u32x4*>(qb + (size_t)(32 * j + row) * rs + 8 * col);
+          no[i] = *reinterpret_cast<const u32x4*>(dob + (size_t)(32 * j + row) * os + 8 * col);
+        }
+      }
+      const int jj = j < nsub ? j : wid;            // any valid sub-tile: NPAD covers every one
+#pragma unroll
+      for (int G = 0; G < 4; ++G) {
+        na[G] = *reinterpret_cast<const f32x4*>(rc_l + 32 * jj + 8 * G + 4 * h);
+        nd[G] = *reinterpret_cast<const f32x4*>(rc_d + 32 * jj + 8 * G + 4 * h);
+      }
+    };
+    prefetch(wid);
+    for (int j = wid; j < nsub; j += NW) {
+      // ---- this wave's own Q / dO sub-tile -> its private LDS region (rows >= N: zeros)
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        const int row = c / CHT, col = c % CHT;
+        *reinterpret_cast<u32x4*>(myQ + row * ROWB + col * 16) = nq[i];
+        *reinterpret_cast<u32x4*>(myO + row * ROWB + col * 16) = no[i];
+      }
+      f32x16 sa, dp;
+#pragma unroll
+      for (int G = 0; G < 4; ++G)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sa[4 * G + e] = na[G][e]; dp[4 * G + e] = nd[G][e]; }
+      prefetch(j + NW);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(myQ + r * ROWB + (16 * s + 8 * h) * 2);
+        const bf16x8 of = *reinterpret_cast<const bf16x8*>(myO + r * ROWB + (16 * s + 8 * h) * 2);
+        sa = mfma32(qf, kS[s], sa);
+        dp = mfma32(of, vS[s], dp);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float p = fast_exp2(sa[e]);
+        if (!key_live) p = 0.f;
+        sa[e] = p;
+        dp[e] = p * dp[e];
+      }
+      f32x16 dq[DB];
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[d][e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pf = acc_to_frag(sa, s);
+        const bf16x8 dsf = acc_to_frag(dp, s);
+        const u32x4 w = __builtin_bit_cast(u32x4, dsf);
+        // private dS image [key r][32 queries] (64-byte rows): queries 16 s + 4 h + 0..3 and 16 s + 8 + 4 h + 0..3
+        *reinterpret_cast<u32x2*>(myS + r * 64 + (16 * s + 4 * h) * 2) = u32x2{w[0], w[1]};
+        *reinterpret_cast<u32x2*>(myS + r * 64 + (16 * s + 8 + 4 * h) * 2) = u32x2{w[2], w[3]};
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          // A = dO^T / Q^T in the accumulator's k order: element j = T[16 s + 8 (j>>2) + 4 h + (j&3)][32 d + r]
+          dv[d] = mfma32(tr_pair(myO, ROWB, 16 * s + 4 * h, 32 * d + 16 * gi, 8, lane), pf, dv[d]);
+          dk[d] = mfma32(tr_pair(myQ, ROWB, 16 * s + 4 * h, 32 * d + 16 * gi, 8, lane), dsf, dk[d]);
+        }
+      }
+      // dQ^T[d][q] += K^T[d][key] dS^T[key][q]: B[k = key 16 s + 8 h + j][col q = r] from the private image
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 bfrag = tr_pair(myS, 64, 16 * s + 8 * h, 16 * gi, 4, lane);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) dq[d] = mfma32(kT[s][d], bfrag, dq[d]);
+      }
+      const int q = 32 * j + r;
+      if (q < N) {
+        bf16_t* drow = dqkv + ((size_t)b * N + q) * rs + (size_t)head * HD;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+          for (int G = 0; G < 4; ++G) {
+            float* wp = wsb + (size_t)q * HD + 32 * d + 8 * G + 4 * h;
+            f32x4 v = {dq[d][4 * G], dq[d][4 * G + 1], dq[d][4 * G + 2], dq[d][4 * G + 3]};
+            if (have_ws) v += *reinterpret_cast<const f32x4*>(wp);
+            if (last)
+              *reinterpret_cast<u32x2*>(drow + 32 * d + 8 * G + 4 * h) =
+                  u32x2{pack2bf(v[0] * scale, v[1] * scale), pack2bf(v[2] * scale, v[3] * scale)};
+            else
+              *reinterpret_cast<f32x4*>(wp) = v;
+          }
+      }
+    }
+    // ---- dK, dV of the group: sum of the 8 waves' partial tiles in a fixed order, written by wave 0
+#pragma unroll
+    for (int which = 0; which < 2; ++which)
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem + RED);
+        const f32x16& src = which ? dv[d] : dk[d];
+#pragma unroll
+        for (int G = 0; G < 4; ++G)
+          *reinterpret_cast<f32x4*>(red + ((wid * 64 + lane) * 16 + 4 * G)) = f32x4{src[4 * G], src[4 * G + 1], src[4 * G + 2], src[4 * G + 3]};
+        __syncthreads();
+        if (wid == 0 && key_live) {
+          bf16_t* drow = dqkv + ((size_t)b * N + key0 + r) * rs + (size_t)head * HD + (size_t)(which ? 2 : 1) * H * HD;
+          const float mul = which ? 1.f : scale;
+#pragma unroll
+          for (int G = 0; G < 4; ++G) {
+            f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s4 += *reinterpret_cast<const f32x4*>(red + ((w * 64 + lane) * 16 + 4 * G));
+            *reinterpret_cast<u32x2*>(drow + 32 * d + 8 * G + 4 * h) =
+                u32x2{pack2bf(s4[0] * mul, s4[1] * mul), pack2bf(s4[2] * mul, s4[3] * mul)};
+          }
+        }
+      }
+    __syncthreads();                               // K / V staging and the scratch are free for the next group
+  }
+}
+
+template <int HD>
+static int run_fused(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, const float* lse, float* ws, bf16_t* dqkv, int B, int N,
+                     int H, float scale, hipStream_t st) {
+  using C = BwdCfg<HD>;
+  const int NPAD = (N + 63) / 64 * 64;
+  float* dq_ws = ws;
+  float* rowc = ws + (size_t)B * H * N * HD;
+  {
+    int blocks = (B * NPAD + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(attn_rowconst_pad_kernel<HD>, dim3(blocks), dim3(256), 0, st, o, dout, lse, rowc, B, N, NPAD, H);
+    OCTMAE_LAUNCH_CHECK();
+  }
+  const int nkb = N / C::KB;
+  if (nkb > 0) {
+    static DynLdsOnce once;
+    if (int rc = once.ensure(reinterpret_cast<const void*>(attn_bwd_fused_kernel<HD>), C::LDS)) return rc;
+    hipLaunchKernelGGL(attn_bwd_fused_kernel<HD>, dim3(B * H), dim3(512), C::LDS, st, qkv, dout, rowc, dq_ws, dqkv, N, NPAD, H, nkb, scale);
+    OCTMAE_LAUNCH_CHECK();
+  }
+  {
+    constexpr int ROWB = HD * 2;
+    constexpr int TAIL_LDS = 2 * 32 * ROWB + 8 * (2 * 32 * ROWB + 32 * 64) + 8 * 64 * 16 * 4;
+    static DynLdsOnce once;
+    if (int rc = once.ensure(reinterpret_cast<const void*>(attn_bwd_tail_kernel<HD>), TAIL_LDS)) return rc;
+    hipLaunchKernelGGL(attn_bwd_tail_kernel<HD>, dim3(B * H), dim3(512), TAIL_LDS, st, qkv, dout, rowc, dq_ws, dqkv, N, NPAD, H,
+                       nkb * C::KB, scale);
+    OCTMAE_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+}  // namespace octmae
+using namespace octmae;
+
+#ifdef BWD_STAMP
+extern "C" int octmae_debug_bwd_stamps(void* host, int nbytes) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bwd_stamp), (size_t)nbytes);
+}
+#endif
+
+extern "C" int octmae_attn_bwd_fused_ws_kib(int B, int N, int H, int HD) {
+  if (B <= 0 || N <= 0 || H <= 0 || (HD != 32 && HD != 64)) return -1;
+  const size_t npad = (size_t)(N + 63) / 64 * 64;
+  const size_t bytes = ((size_t)B * H * N * HD + 2 * (size_t)B * H * npad) * 4;
+  const size_t kib = (bytes + 1023) / 1024;
+  return kib > 0x7fffffffull ? -2 : (int)kib;
+}
+
+extern "C" int octmae_attn_bwd_fused(const void* qkv, const void* o, const void* dout, const float* lse, void* ws, void* dqkv, int B,
+                                     int N, int H, int HD, float scale, void* stream) {
+  OCTMAE_CHECK_ARG(qkv && o && dout && lse && ws && dqkv && B > 0 && N > 0 && H > 0 && (HD == 64 || HD == 32));
+  OCTMAE_CHECK_ARG(((size_t)N * 3 * H * HD * 2) < 0xFFFFFFFFull);      // one sample's qkv rows within a 32-bit buffer range
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bf16_t* q = reinterpret_cast<const bf16_t*>(qkv);
+  const bf16_t* oo = reinterpret_cast<const bf16_t*>(o);
+  const bf16_t* dd = reinterpret_cast<const bf16_t*>(dout);
+  bf16_t* out = reinterpret_cast<bf16_t*>(dqkv);
+  float* w = reinterpret_cast<float*>(ws);
+  return HD == 64 ? run_fused<64>(q, oo, dd, lse, w, out, B, N, H, scale, st) : run_fused<32>(q, oo, dd, lse, w, out, B, N, H, scale, st);
+}

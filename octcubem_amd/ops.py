@@ -274,14 +274,32 @@ def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, HD: int, scale: float, o
     return o, lse
 
 
-def attn_bwd(qkv, o, dout, lse, B, N, H, HD, scale):
+# Which backward runs per head_dim: the single-pass kernel (csrc/attn_bwd.hip) or the dQ + dK/dV kernel pair (csrc/attn.hip).
+# Measured on MI355X (tools/attn_bwd_ab.py, same process, interleaved): head_dim 32 (decoder, N = 5121) fused 4-6 % faster,
+# head_dim 64 (encoder N = 1281, fine-tune N = 5121) the pair 10-13 % faster -- the fused form is limited by LDS traffic there.
+ATTN_BWD_FUSED = {32: True, 64: False}
+
+
+def attn_bwd(qkv, o, dout, lse, B, N, H, HD, scale, fused: Optional[bool] = None):
+    """Gradient of attn_fwd w.r.t. the packed qkv.  Algorithmic work ("x3" in total): 4 matrix products =
+    8 B H N^2 HD flop (dP, dV, dK, dQ); the recomputation of S is not counted."""
     dqkv = torch.empty_like(qkv)
-    rowc = torch.empty((2, B, H, N), dtype=F32, device=qkv.device)      # -lse*log2e | -rowsum(dO * O)
     st = _stream()
-    # Algorithmic backward ("x3"): 4 matmuls = 8 B H N^2 HD flop (dP, dV, dK, dQ; the recomputation of S is not
-    # counted).  The two-kernel form executes 7: dq 3 (S, dP, dQ), dkv 4 (S, dP, dV, dK); the algorithmic 4 are booked
-    # 1.6 / 2.4 in proportion.  The dQ kernel also produces the row constants (rowc) that the dK/dV kernel reads.
     unit = 2.0 * B * H * N * N * HD
+    if ATTN_BWD_FUSED[HD] if fused is None else fused:
+        from ._lib import load
+        kib = load().octmae_attn_bwd_fused_ws_kib(B, N, H, HD)
+        if kib < 0:
+            raise RuntimeError("octmae_attn_bwd_fused_ws_kib: unsupported shape")
+        ws = torch.empty((kib * 256,), dtype=F32, device=qkv.device)     # dQ fp32 + padded row constants (contents irrelevant)
+        # executes 5 products (S once); plus an fp32 read-modify-write of dQ per key block
+        _launch(f"attn_bwd_fused_hd{HD}", 4 * unit, 2.0 * 6 * B * N * H * HD,
+                lambda: call("octmae_attn_bwd_fused", qkv.data_ptr(), o.data_ptr(), dout.data_ptr(), lse.data_ptr(), ws.data_ptr(),
+                             dqkv.data_ptr(), B, N, H, HD, float(scale), st), exec_flops=5 * unit)
+        return dqkv
+    rowc = torch.empty((2, B, H, N), dtype=F32, device=qkv.device)      # -lse*log2e | -rowsum(dO * O)
+    # The two-kernel form executes 7 products: dq 3 (S, dP, dQ), dkv 4 (S, dP, dV, dK); the algorithmic 4 are booked
+    # 1.6 / 2.4 in proportion.  The dQ kernel also produces the row constants (rowc) that the dK/dV kernel reads.
     _launch(f"attn_bwd_dq_hd{HD}", 1.6 * unit, 2.0 * 6 * B * N * H * HD,
             lambda: call("octmae_attn_bwd_dq_rowconst", qkv.data_ptr(), o.data_ptr(), dout.data_ptr(), lse.data_ptr(), rowc.data_ptr(),
                          dqkv.data_ptr(), B, N, H, HD, float(scale), st), exec_flops=3 * unit)

@@ -306,6 +306,43 @@ def test_attention_fwd_bwd(HD, N, optimistic):
             assert rel(got[:, :, i], ref[:, :, i]) < 1.5e-2, name     # bf16 P, dS and outputs
 
 
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("HD,N", [(64, 5121), (32, 5121), (32, 1024), (64, 512), (32, 545), (64, 257)])
+def test_attention_fwd_bwd_long_sequences(HD, N, fused):
+    """Full-length sequences of the decoder (N = 5121, head_dim 32) and of the fine-tune ViT (N = 5121, head_dim 64), plus
+    lengths that are whole key blocks of the fused backward (512 / 256 keys) or leave a multi-group tail, against fp64 on the
+    same bf16-rounded operands; both backward forms."""
+    B, H = 1, 2
+    g = torch.Generator().manual_seed(N * 5 + HD)
+    qkv = bf(torch.randn(B * N, 3 * H * HD, generator=g)).to(DEV)
+    do = bf(torch.randn(B * N, H * HD, generator=g)).to(DEV)
+    o, lse = ops.attn_fwd(qkv, B, N, H, HD, HD ** -0.5)
+    qd = qkv.double().requires_grad_(True)
+    o_ref, lse_ref = attn_ref(qd, B, N, H, HD)
+    assert rel(o, o_ref) < 4e-3
+    o_ref.backward(do.double())
+    dqkv = ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, HD ** -0.5, fused=fused)
+    got = dqkv.double().view(B, N, 3, H * HD); ref = qd.grad.view(B, N, 3, H * HD)
+    errs = {name: rel(got[:, :, i], ref[:, :, i]) for i, name in enumerate("qkv")}
+    print(f"attention backward HD={HD} N={N} fused={fused}: rel-L2 " + ", ".join(f"d{k} {v:.2e}" for k, v in errs.items()))
+    assert max(errs.values()) < 1.5e-2, errs
+
+
+def test_attention_backward_fused_equals_two_kernel_form_closely():
+    """Same math, different summation order and one bf16 rounding of dS instead of two: the two forms agree far inside their
+    common distance to fp64."""
+    for HD, N, B, H in [(32, 1281, 2, 4), (64, 1281, 2, 4), (32, 197, 3, 2), (64, 50, 2, 2)]:
+        g = torch.Generator().manual_seed(HD + N)
+        qkv = bf(torch.randn(B * N, 3 * H * HD, generator=g)).to(DEV)
+        do = bf(torch.randn(B * N, H * HD, generator=g)).to(DEV)
+        o, lse = ops.attn_fwd(qkv, B, N, H, HD, HD ** -0.5)
+        a = ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, HD ** -0.5, fused=True)
+        b_ = ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, HD ** -0.5, fused=False)
+        assert rel(a, b_) < 6e-3, (HD, N, rel(a, b_))
+        a2 = ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, HD ** -0.5, fused=True)
+        assert torch.equal(a, a2)                                       # no atomics: bit-reproducible
+
+
 @pytest.mark.parametrize("HD,N", [(64, 333), (32, 1281), (64, 129), (32, 64)])
 def test_attention_backward_fused_row_constants(HD, N):
     """octmae_attn_bwd (dQ kernel computes and publishes the row constants) against the three-launch form
@@ -333,7 +370,7 @@ def test_attention_backward_fused_row_constants(HD, N):
     assert torch.equal(rc1[0], rc3[0])                                   # -lse * log2e: the same product
     assert float((rc1[1] - rc3[1]).abs().max()) <= 1e-5 * float(rc3[1].abs().max()) + 1e-6
     assert rel(d1, d3) < 1e-3
-    assert torch.equal(ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, scale), d1)     # the host wrapper takes the fused path
+    assert torch.equal(ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, scale, fused=False), d1)     # the host wrapper's two-kernel form
 
 
 @pytest.mark.parametrize("HD", [64, 32])
