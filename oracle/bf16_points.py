@@ -1,0 +1,154 @@
+"""TEST INFRASTRUCTURE (see oracle/__init__): a CPU model of ONE pre-norm transformer Block -- forward and backward of
+Pre-training/custom_util/video_vit.py:141-184 (Block), :86-138 (Attention), timm Mlp -- evaluated in float64 with a bfloat16
+rounding inserted at exactly the points where the HIP path (octcubem_amd.ops.BlockFn -> csrc/*.hip) rounds:
+
+  forward   y1 = bf(LN1 x) ; qkv = bf(y1 Wqkv^T + b) ; attention with q * scale*log2e rounded to bf16, P rounded to bf16 for the
+            P V product only (the row sum uses the unrounded P), o = bf(O / l) ; x2 = x + o Wp^T + b (fp32) ;
+            y2 = bf(LN2 x2) ; pre = bf(y2 W1^T + b1) ; act = bf(gelu(pre)) ; x3 = x2 + act W2^T + b2 (fp32)
+  backward  every gradient entering a GEMM is bf16 (d3b, dpre, dy2, dx2b, do, dqkv, dy1); dpre = bf(bf(d3b W2) * gelu'(pre));
+            attention: P and dS rounded to bf16 for their products, K * scale*log2e rounded to bf16 in the kernels that keep the
+            key on the lane (fused backward, dK/dV kernel), Q * scale*log2e in the dQ kernel of the two-kernel form;
+            LayerNorm backward, residual adds, bias / weight gradients in fp32.
+  weights   the MFMA operands are the bf16 mirror of the fp32 master weights.
+
+GELU and GELU' are the epilogues' polynomials (exact_gelu=False; their fits are bounded at 7.8e-5 / 4.4e-4 absolute, and the
+test prices what they cost against the erf forms).  What remains between this model and the HIP result is accumulation order
+(fp32 vs float64), the hardware exp2, and rare rounding flips of values that land within 1e-7 of a bf16 tie.  The GPU test
+(tests/test_gpu_rounding_model.py) requires <= 1e-3 relative for every output, which separates "bf16 operand rounding" from
+"kernel arithmetic error": the plain fp32 oracle differs from both by the 2^-9-per-operation rounding the north star's 1e-3
+bound cannot absorb element-wise (loss-level quantities do meet 1e-3, see tests/test_gpu_fullsize_pins.py).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+D = torch.float64
+LOG2E = 1.4426950408889634
+
+
+def bf(x: torch.Tensor) -> torch.Tensor:
+    """Round to bfloat16 (nearest even) and return as float64."""
+    return x.to(torch.float32).to(torch.bfloat16).to(D)
+
+
+def ln_fwd(x, g, b, eps):
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(var + eps)
+    xhat = (x - mu) * rstd
+    return xhat * g + b, xhat, rstd
+
+
+def ln_bwd(dy, xhat, rstd, g):
+    gy = dy * g
+    dx = rstd * (gy - gy.mean(-1, keepdim=True) - xhat * (gy * xhat).mean(-1, keepdim=True))
+    return dx, (dy * xhat).reshape(-1, dy.shape[-1]).sum(0), dy.reshape(-1, dy.shape[-1]).sum(0)
+
+
+def gelu(x):
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def dgelu(x):
+    return 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2.0 * math.pi)
+
+
+def gelu_poly(x):
+    """The GEMM epilogue's GELU (csrc/common.hpp gelu_f): x * (0.5 + u P(u^2)), u = clamp(x, +-4.5), |Phi error| <= 7.8e-5."""
+    u = x.clamp(-4.5, 4.5)
+    t = u * u
+    p = torch.full_like(x, -7.715688019e-10)
+    for c in (7.192630176e-08, -2.879689972e-06, 6.548595686e-05, -9.478268993e-04, 9.327514321e-03, -6.568239007e-02,
+              3.986432605e-01):
+        p = p * t + c
+    return x * (u * p + 0.5)
+
+
+def dgelu_poly(x):
+    """The fc2-dgrad epilogue's GELU' (csrc/common.hpp dgelu_f): 0.5 + u Q(u^2), u = clamp(x, +-5), |error| <= 4.4e-4."""
+    u = x.clamp(-5.0, 5.0)
+    t = u * u
+    q = torch.full_like(x, -8.945184002e-12)
+    for c in (1.221804868e-09, -7.286091231e-08, 2.499930865e-06, -5.482182127e-05, 8.080908045e-04, -8.191250186e-03,
+              5.702680522e-02, -2.631234724e-01, 7.970332990e-01):
+        q = q * t + c
+    return u * q + 0.5
+
+
+def block_forward_backward(P: Dict[str, torch.Tensor], x: torch.Tensor, dx3: torch.Tensor, num_heads: int, eps: float = 1e-6,
+                           fused_bwd: bool = True, exact_gelu: bool = False):
+    """P: the Block's parameters by their reference names (norm1.weight, attn.q.weight, ..., mlp.fc2.bias), fp32.
+    x, dx3: [B, N, C] fp32.  Returns (x3, dx, grads) in float64."""
+    B, N, C = x.shape
+    H = num_heads
+    hd = C // H
+    scale = hd ** -0.5
+    F = torch.float32
+    sc2 = torch.tensor(scale, dtype=F) * torch.tensor(LOG2E, dtype=F)      # the kernels form scale*log2e as an fp32 product
+    p = {k: v.to(D) for k, v in P.items()}
+    x = x.to(D); dx3 = dx3.to(D)
+    wqkv = bf(torch.cat([p["attn.q.weight"], p["attn.k.weight"], p["attn.v.weight"]], 0))
+    bqkv = torch.cat([p["attn.q.bias"], p["attn.k.bias"], p["attn.v.bias"]], 0)
+    wp, w1, w2 = bf(p["attn.proj.weight"]), bf(p["mlp.fc1.weight"]), bf(p["mlp.fc2.weight"])
+
+    # ---------------- forward
+    y1f, xh1, rs1 = ln_fwd(x, p["norm1.weight"], p["norm1.bias"], eps)
+    y1 = bf(y1f)
+    qkv = bf(y1 @ wqkv.T + bqkv)                                            # [B, N, 3C]
+    q, k, v = (t.reshape(B, N, H, hd).transpose(1, 2) for t in qkv.split(C, dim=-1))     # [B, H, N, hd]
+    qs = (q.to(F) * sc2).to(torch.bfloat16).to(D)                           # fp32 product, then bf16, as scale_frag does
+    S2 = qs @ k.transpose(-1, -2)                                           # exp2-domain scores
+    Pm = torch.exp2(S2)                                                     # optimistic forward: no running max
+    l = Pm.sum(-1, keepdim=True)
+    o = bf((bf(Pm) @ v) / l)                                                # [B, H, N, hd]
+    lse = torch.log2(l.squeeze(-1)) * math.log(2.0)                         # natural log, as the kernel stores it
+    lse = lse.to(torch.float32).to(D)
+    o2 = o.transpose(1, 2).reshape(B, N, C)
+    x2 = x + o2 @ wp.T + p["attn.proj.bias"]
+    y2f, xh2, rs2 = ln_fwd(x2, p["norm2.weight"], p["norm2.bias"], eps)
+    y2 = bf(y2f)
+    pre = bf(y2 @ w1.T + p["mlp.fc1.bias"])
+    act = bf(gelu(pre) if exact_gelu else gelu_poly(pre))
+    x3 = x2 + act @ w2.T + p["mlp.fc2.bias"]
+
+    # ---------------- backward
+    G = {}
+    d3b = bf(dx3)
+    G["mlp.fc2.weight"] = (d3b.reshape(-1, C).T @ act.reshape(-1, act.shape[-1]))
+    G["mlp.fc2.bias"] = dx3.reshape(-1, C).sum(0)
+    dpre = bf(bf(d3b @ w2) * (dgelu(pre) if exact_gelu else dgelu_poly(pre)))
+    G["mlp.fc1.bias"] = dpre.reshape(-1, dpre.shape[-1]).sum(0)
+    G["mlp.fc1.weight"] = dpre.reshape(-1, dpre.shape[-1]).T @ y2.reshape(-1, C)
+    dy2 = bf(dpre @ w1)
+    dln2, G["norm2.weight"], G["norm2.bias"] = ln_bwd(dy2, xh2, rs2, p["norm2.weight"])
+    dx2 = dx3 + dln2
+    dx2b = bf(dx2)
+    G["attn.proj.bias"] = dx2.reshape(-1, C).sum(0)
+    G["attn.proj.weight"] = dx2b.reshape(-1, C).T @ o2.reshape(-1, C)
+    do = bf(dx2b @ wp).reshape(B, N, H, hd).transpose(1, 2)                 # [B, H, N, hd]
+    delta = (do * o).sum(-1, keepdim=True).to(torch.float32).to(D)
+    nl = (-(lse.to(torch.float32) * torch.tensor(LOG2E, dtype=torch.float32))).to(D).unsqueeze(-1)   # -lse*log2e (fp32 product)
+    ks = (k.to(F) * sc2).to(torch.bfloat16).to(D)
+    Pk = torch.exp2(q @ ks.transpose(-1, -2) + nl)                          # key-on-the-lane kernels: K pre-scaled
+    dPk = do @ v.transpose(-1, -2) - delta
+    dSk = Pk * dPk
+    dV = bf(Pk).transpose(-1, -2) @ do
+    dK = scale * (bf(dSk).transpose(-1, -2) @ q)
+    if fused_bwd:
+        dQ = scale * (bf(dSk) @ k)
+    else:                                                                   # the dQ kernel of the pair pre-scales Q
+        Pq = torch.exp2(qs @ k.transpose(-1, -2) + nl)
+        dQ = scale * (bf(Pq * dPk) @ k)
+    dqkv = bf(torch.cat([t.transpose(1, 2).reshape(B, N, C) for t in (dQ, dK, dV)], -1))
+    gb = dqkv.reshape(-1, 3 * C).sum(0)
+    gw = dqkv.reshape(-1, 3 * C).T @ y1.reshape(-1, C)
+    for i, nme in enumerate("qkv"):
+        G[f"attn.{nme}.weight"] = gw[i * C:(i + 1) * C]
+        G[f"attn.{nme}.bias"] = gb[i * C:(i + 1) * C]
+    dy1 = bf(dqkv @ wqkv)
+    dln1, G["norm1.weight"], G["norm1.bias"] = ln_bwd(dy1, xh1, rs1, p["norm1.weight"])
+    dx = dx2 + dln1
+    return x3, dx, G
