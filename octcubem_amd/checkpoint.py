@@ -105,11 +105,25 @@ def load_pretrained(model, checkpoint, strict=False, filter_keys=(), smaller_int
     flash_model = any(".mixer.Wqkv." in k for k in model.state_dict())
     w = sd.get("patch_embed.proj.weight")
     if w is not None and w.dim() == 4 and model.patch_embed.proj.weight.dim() == 5:
-        if w.shape[1] != model.patch_embed.proj.weight.shape[1]:        # RGB 2-D weights -> single-channel volumes
-            sd["patch_embed.proj.weight"] = w.sum(dim=1, keepdim=True)
-        convert_patchembed_2Dto3D(sd)
-        t = model.patch_embed.proj.weight.shape[2]
-        sd["patch_embed.proj.weight"] = sd["patch_embed.proj.weight"].repeat(1, 1, t, 1, 1) / t     # inflate over t_patch_size
+        own_w = model.patch_embed.proj.weight                            # [O, in_chans, t_patch, p, p]
+        if own_w.shape[1] == 1 and w.shape[1] == own_w.shape[2]:
+            # The reference's RETFound / ImageNet initialisation (load_model_retfound[_flash_attn],
+            # Pre-training/custom_util/misc.py:498-523): convert_patchembed_2Dto3D = unsqueeze(1), i.e. the 3 RGB kernels of
+            # [O, 3, p, p] become the 3 temporal taps of the single-channel [O, 1, 3, p, p] kernel.
+            convert_patchembed_2Dto3D(sd)
+        else:                                                            # any other channel / tap count: channel sum, equal taps
+            if w.shape[1] != own_w.shape[1]:
+                sd["patch_embed.proj.weight"] = w.sum(dim=1, keepdim=True)
+            convert_patchembed_2Dto3D(sd)
+            t = own_w.shape[2]
+            sd["patch_embed.proj.weight"] = sd["patch_embed.proj.weight"].repeat(1, 1, t, 1, 1) / t
+        hr = getattr(model, "high_res_patch_embed", None)
+        if hr is not None and "high_res_patch_embed.proj.weight" not in sd \
+                and tuple(hr.proj.weight.shape) == tuple(sd["patch_embed.proj.weight"].shape):
+            # the reference copies the inflated embedding into the 512^2 branch as well (:520-522)
+            sd["high_res_patch_embed.proj.weight"] = sd["patch_embed.proj.weight"].clone()
+            if "patch_embed.proj.bias" in sd:
+                sd["high_res_patch_embed.proj.bias"] = sd["patch_embed.proj.bias"].clone()
     if "pos_embed" in sd and hasattr(model, "pos_embed_spatial"):
         interpolate_pos_embed_2Dto3D(model, sd)
     if hasattr(model, "pos_embed_spatial"):

@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from . import ops
 from .arena import get_arena
+from . import video_vit
 from .video_vit import TimmBlock as Block, TimmPatchEmbed as PatchEmbed, layer_norm
 
 
@@ -33,21 +34,45 @@ class MaskedAutoencoderViT(nn.Module):
     """Masked Autoencoder with VisionTransformer backbone"""
 
     def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=1024, depth=24, num_heads=16, decoder_embed_dim=512,
-                 decoder_depth=8, decoder_num_heads=16, mlp_ratio=4.0, norm_layer=nn.LayerNorm, norm_pix_loss=False):
+                 decoder_depth=8, decoder_num_heads=16, mlp_ratio=4.0, norm_layer=nn.LayerNorm, norm_pix_loss=False,
+                 use_flash_attn=False, flash_compat=False, no_qkv_bias=False, drop_rate=0.0, attn_drop_rate=0.0,
+                 drop_path_rate=0.0, input_size=None, **kwargs):
+        """``use_flash_attn=True`` builds the twin of OCTCube/models_mae_flash_attn.py (:70-176): blocks from the
+        ``create_block`` factory (state_dict keys ``blocks.i.mixer.Wqkv / out_proj``), the ``x, residual = blk(x, residual)``
+        loop and hence the dropped final residual of the flash path; ``input_size`` is that file's
+        name for ``img_size``.  ``flash_compat=True`` keeps the timm layout and only drops the last block's residual.
+        Attention itself is always the gfx950 kernel."""
         super().__init__()
+        if input_size is not None:
+            img_size = input_size
         self.in_chans = in_chans
+        self.use_flash_attn = bool(use_flash_attn)
+        self.flash_compat = bool(flash_compat)
         self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        self.patch_embed.input_size = self.patch_embed.img_size          # attribute name of the flash file's PatchEmbed (:48-68)
+        self.input_size = self.patch_embed.img_size
         num_patches = self.patch_embed.num_patches
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim), requires_grad=False)
-        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, qkv_bias=True, qk_scale=None, norm_layer=norm_layer)
-                                     for _ in range(depth)])
+
+        def stack(dim, heads, n):
+            if not self.use_flash_attn:
+                return nn.ModuleList([Block(dim, heads, mlp_ratio, qkv_bias=True, qk_scale=None, norm_layer=norm_layer)
+                                      for _ in range(n)])
+            dpr = [x.item() for x in torch.linspace(0, drop_path_rate, n)]
+            return nn.ModuleList([
+                video_vit.create_block(dim, heads, mlp_ratio, not no_qkv_bias, drop_rate, attn_drop_rate,
+                                       drop_path1=dpr[i - 1] if i > 0 else 0.0, drop_path2=dpr[i], norm_layer=norm_layer,
+                                       act_layer=nn.GELU, use_flash_attn=True, fused_bias_fc=False, fused_mlp=False,
+                                       fused_dropout_add_ln=False, layer_idx=i, n_layer=n, last_layer_subset=False)
+                for i in range(n)])
+
+        self.blocks = stack(embed_dim, num_heads, depth)
         self.norm = norm_layer(embed_dim)
         self.decoder_embed = nn.Linear(embed_dim, decoder_embed_dim, bias=True)
         self.mask_token = nn.Parameter(torch.zeros(1, 1, decoder_embed_dim))
         self.decoder_pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, decoder_embed_dim), requires_grad=False)
-        self.decoder_blocks = nn.ModuleList([Block(decoder_embed_dim, decoder_num_heads, mlp_ratio, qkv_bias=True, qk_scale=None,
-                                                   norm_layer=norm_layer) for _ in range(decoder_depth)])
+        self.decoder_blocks = stack(decoder_embed_dim, decoder_num_heads, decoder_depth)
         self.decoder_norm = norm_layer(decoder_embed_dim)
         self.decoder_pred = nn.Linear(decoder_embed_dim, patch_size ** 2 * in_chans, bias=True)
         self.norm_pix_loss = norm_pix_loss
@@ -105,6 +130,16 @@ class MaskedAutoencoderViT(nn.Module):
         return ops.LinearFn.apply(x, arena.lp_view(lin.weight), arena.f32_view(lin.bias), lambda: arena.grad_view(lin.weight),
                                   lambda: arena.grad_view(lin.bias), out_f32, lin.weight, lin.bias)
 
+    def _run_blocks(self, blocks, x):
+        if self.use_flash_attn:                       # OCTCube/models_mae_flash_attn.py: residual = None; x, residual = blk(x, residual)
+            residual = None
+            for blk in blocks:
+                x, residual = blk(x, residual)
+            return x
+        for i, blk in enumerate(blocks):
+            x = blk(x, final_residual=not (self.flash_compat and i == len(blocks) - 1))
+        return x
+
     def forward_encoder(self, x, mask_ratio, noise=None):
         N = x.shape[0]
         L = self.patch_embed.num_patches
@@ -115,8 +150,7 @@ class MaskedAutoencoderViT(nn.Module):
         tok = self.patch_embed.embed_tokens(x, ids_keep)                               # kept patches only (output-identical)
         pe = self.pos_embed[0]
         xs = ops.EncAssembleFn.apply(tok, pe[1:], self.cls_token, pe[:1].view(1, 1, -1), ids_keep)   # fp32 [N, 1+keep, D]
-        for blk in self.blocks:
-            xs = blk(xs)
+        xs = self._run_blocks(self.blocks, xs)
         xs = layer_norm(self.norm, xs)
         self._ids_keep = ids_keep
         return xs, mask, ids_restore
@@ -130,8 +164,7 @@ class MaskedAutoencoderViT(nn.Module):
         emb = self._linear(self.decoder_embed, x.reshape(-1, x.shape[-1]))             # bf16 [N*(1+keep), Dd], cls row included
         dpe = self.decoder_pos_embed[0]
         xd = ops.DecAssembleFn.apply(emb, self.mask_token, dpe[1:], None, dpe[:1].view(1, 1, -1), ids_restore, ids_keep)
-        for blk in self.decoder_blocks:
-            xd = blk(xd)
+        xd = self._run_blocks(self.decoder_blocks, xd)
         xd = layer_norm(self.decoder_norm, xd)
         pred_full = self._linear(self.decoder_pred, xd, out_f32=True)
         self._pred_full = pred_full
@@ -176,3 +209,9 @@ def mae_vit_base_patch16_dec512d8b(**kwargs):
 
 mae_vit_large_patch16 = mae_vit_large_patch16_dec512d8b
 mae_vit_base_patch16 = mae_vit_base_patch16_dec512d8b
+
+
+def flash_attn_mae_vit_large_patch16(**kwargs):
+    """The factory of OCTCube/models_mae_flash_attn.py (its class defaults to use_flash_attn=True)."""
+    kwargs.setdefault("use_flash_attn", True)
+    return mae_vit_large_patch16_dec512d8b(**kwargs)

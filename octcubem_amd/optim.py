@@ -36,7 +36,9 @@ class _MultiTensorTable:
         self.table = torch.frombuffer(raw, dtype=torch.uint8).clone().to(dev)
         self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=dev)
         self.chunk_off = torch.tensor(co, dtype=torch.int64, device=dev)
-        self.key = tuple((p.data_ptr(), g.data_ptr() if g is not None else 0) for p, g in zip(ps, gs))
+        # every pointer the table holds is part of its identity: a loaded optimizer state replaces exp_avg / exp_avg_sq
+        self.key = tuple((p.data_ptr(), g.data_ptr() if g is not None else 0, m.data_ptr() if m is not None else 0,
+                          v.data_ptr() if v is not None else 0) for p, g, m, v in zip(ps, gs, ms, vs))
 
 
 def grad_norm_and_coef(params, max_norm: Optional[float], cache: dict):
@@ -45,7 +47,7 @@ def grad_norm_and_coef(params, max_norm: Optional[float], cache: dict):
     ps = [p for p in params if p.grad is not None]
     if not ps:
         return torch.tensor(0.0), None
-    key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
+    key = tuple((p.data_ptr(), p.grad.data_ptr(), 0, 0) for p in ps)
     tab = cache.get("norm")
     if tab is None or tab.key != key:
         tab = _MultiTensorTable([p.data for p in ps], [p.grad for p in ps], [None] * len(ps), [None] * len(ps))
@@ -66,6 +68,11 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._tables = {}
         self._grad_scale: Optional[torch.Tensor] = None   # device scalar multiplied into every gradient
+
+    def load_state_dict(self, state_dict):
+        """The moment buffers are replaced: drop the device pointer tables (they are rebuilt on the next step)."""
+        super().load_state_dict(state_dict)
+        self._tables = {}
 
     def set_grad_scale(self, scale: Optional[torch.Tensor]):
         self._grad_scale = scale
@@ -90,11 +97,16 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-            group.setdefault("_step", 0)
+            if "_step" not in group:
+                # a state loaded from torch.optim.AdamW carries the count per parameter ("step", int or tensor), not per
+                # group: continue from it so that the bias correction does not restart
+                steps = [self.state[p].get("step", 0) for p in ps]
+                group["_step"] = int(max(float(s_) for s_ in steps)) if steps else 0
             group["_step"] += 1
             for p in ps:
                 self.state[p]["step"] = group["_step"]
-            key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
+            key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
+                         self.state[p]["exp_avg_sq"].data_ptr()) for p in ps)
             tab = self._tables.get(gi)
             if tab is None or tab.key != key:
                 tab = _MultiTensorTable([p.data for p in ps], [p.grad for p in ps], [self.state[p]["exp_avg"] for p in ps],

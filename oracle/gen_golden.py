@@ -126,8 +126,40 @@ def install_shims():
         def forward(self, x):
             return self.proj(x).flatten(2).transpose(1, 2)
 
+    class TimmVisionTransformer(nn.Module):   # timm 0.3.2 vision_transformer.VisionTransformer (restated: timm is un-vendored)
+        def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12, num_heads=12,
+                     mlp_ratio=4.0, qkv_bias=False, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0,
+                     hybrid_backbone=None, norm_layer=nn.LayerNorm):
+            super().__init__()
+            self.num_classes = num_classes
+            self.num_features = self.embed_dim = embed_dim
+            self.patch_embed = TimmPatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+            num_patches = self.patch_embed.num_patches
+            self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+            self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
+            self.pos_drop = nn.Dropout(p=drop_rate)
+            dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+            self.blocks = nn.ModuleList([
+                TimmBlock(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate,
+                          attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer) for i in range(depth)])
+            self.norm = norm_layer(embed_dim)
+            self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+
+        def forward_features(self, x):
+            B = x.shape[0]
+            x = self.patch_embed(x)
+            x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1)
+            x = self.pos_drop(x + self.pos_embed)
+            for blk in self.blocks:
+                x = blk(x)
+            return self.norm(x)[:, 0]
+
+        def forward(self, x):
+            return self.head(self.forward_features(x))
+
     layers.to_2tuple = to_2tuple; tl.to_2tuple = to_2tuple
     vt.DropPath = DropPath; vt.Mlp = Mlp; vt.PatchEmbed = TimmPatchEmbed; vt.Block = TimmBlock
+    vt.VisionTransformer = TimmVisionTransformer
     tv = mod("torchvision"); tvt = mod("torchvision.transforms"); tv.transforms = tvt
 
     class _Permissive:      # OCTCube/util/misc.py builds image transforms at import time (e.g. tf.Lambda); never called here

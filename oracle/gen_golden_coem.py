@@ -5,7 +5,10 @@ Runs retinal-COEM/src/open_clip/loss.py ``ClipLoss`` (loaded as a single file; t
 un-vendored dependencies) on seeded L2-normalised features:
   * world_size 1: plain labels and ``correct_label`` (two samples sharing identical en-face features);
   * world_size 2 over gloo, 2 spawned processes, every (local_loss, gather_with_grad) combination: per-rank loss and the
-    gradients of that rank's features and of logit_scale.
+    gradients of that rank's features and of logit_scale;
+  * ``ThreeModalityClipLoss`` (loss.py:230-385) the same way: world 1 with all / some / no samples of a modality present, and
+    world 2 for local_loss = False with and without gather_with_grad (with local_loss = True the reference builds its labels from
+    the GLOBAL sample count and its cross-entropy raises on the local logits: not a usable mode).
 """
 import importlib.util
 import os
@@ -38,6 +41,28 @@ def feats(seed, n, d=32, dup=False):
     return a, b
 
 
+def feats3(seed, n, d=32):
+    g = torch.Generator().manual_seed(seed)
+    f = [torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=-1) for _ in range(3)]
+    w1 = (torch.rand(n, generator=g) > 0.3).float(); w2 = (torch.rand(n, generator=g) > 0.4).float()
+    return f[0], f[1], f[2], w1, w2
+
+
+def run3(ref, rank, world, local_loss, gwg, seed, n, w_override=None):
+    a, b, c, w1, w2 = feats3(seed, n)
+    if w_override is not None:
+        w1, w2 = w_override(w1, w2)
+    for t in (a, b, c):
+        t.requires_grad_(True)
+    ls = [torch.tensor(np.log(1 / t_), dtype=torch.float32, requires_grad=True) for t_ in (0.07, 0.05, 0.1)]
+    loss = ref.ThreeModalityClipLoss(local_loss=local_loss, gather_with_grad=gwg, rank=rank, world_size=world)(
+        a, b, c, ls[0].exp(), ls[1].exp(), ls[2].exp(), w1, w2)
+    loss.backward()
+    z = lambda t: (t.grad if t.grad is not None else torch.zeros_like(t)).numpy()
+    return {"loss": loss.detach().numpy(), "ga": z(a), "gb": z(b), "gc": z(c), "gls": np.array([float(z(l)) for l in ls]),
+            "w1": w1.numpy(), "w2": w2.numpy()}
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -57,6 +82,10 @@ def worker(rank, world, port, q):
             tag = f"w2/ll{int(local_loss)}_gg{int(gwg)}/r{rank}"
             out[tag + "/loss"] = loss.detach().numpy(); out[tag + "/ga"] = a.grad.numpy(); out[tag + "/gb"] = b.grad.numpy()
             out[tag + "/gls"] = ls.grad.numpy()
+    for local_loss, gwg in ((False, False), (False, True)):
+        r = run3(ref, rank, world, local_loss, gwg, 300 + rank, 4)
+        for k, v in r.items():
+            out[f"w2m3/ll{int(local_loss)}_gg{int(gwg)}/r{rank}/{k}"] = v
     q.put(out)
     dist.barrier()
     dist.destroy_process_group()
@@ -73,6 +102,12 @@ def main():
         loss.backward()
         save[f"w1/{name}/loss"] = loss.detach().numpy(); save[f"w1/{name}/ga"] = a.grad.numpy(); save[f"w1/{name}/gb"] = b.grad.numpy()
         save[f"w1/{name}/gls"] = ls.grad.numpy()
+    cases = {"all": lambda w1, w2: (torch.ones_like(w1), torch.ones_like(w2)), "some": None,
+             "none2": lambda w1, w2: (w1, torch.zeros_like(w2))}
+    for name, ov in cases.items():
+        r = run3(ref, 0, 1, False, False, 55, 7, ov)
+        for k, v in r.items():
+            save[f"w1m3/{name}/{k}"] = v
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

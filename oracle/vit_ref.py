@@ -177,8 +177,10 @@ def mae2d_init(cfg: MAE2DConfig, seed=0, bias_std=0.02):
     return P
 
 
-def timm_block(x, P, prefix, num_heads, eps):
-    """timm 0.3.2 Block: x + attn(norm1(x)); x + mlp(norm2(x)); Attention with one fused qkv Linear."""
+def timm_block(x, P, prefix, num_heads, eps, final_residual=True):
+    """timm 0.3.2 Block: x + attn(norm1(x)); x + mlp(norm2(x)); Attention with one fused qkv Linear.
+    final_residual=False: the MLP branch alone -- what flash-attn 2.5.2's prenorm Block returns as ``hidden_states`` and the
+    reference's flash models hand to their final norm (OCTCube/models_mae_flash_attn.py; restated, parity unpinned)."""
     B, N, C = x.shape
     hd = C // num_heads
     h = F.layer_norm(x, (C,), P[f"{prefix}.norm1.weight"], P[f"{prefix}.norm1.bias"], eps)
@@ -189,7 +191,8 @@ def timm_block(x, P, prefix, num_heads, eps):
     x = x + F.linear(a, P[f"{prefix}.attn.proj.weight"], P[f"{prefix}.attn.proj.bias"])
     h = F.layer_norm(x, (C,), P[f"{prefix}.norm2.weight"], P[f"{prefix}.norm2.bias"], eps)
     h = F.gelu(F.linear(h, P[f"{prefix}.mlp.fc1.weight"], P[f"{prefix}.mlp.fc1.bias"]))
-    return x + F.linear(h, P[f"{prefix}.mlp.fc2.weight"], P[f"{prefix}.mlp.fc2.bias"])
+    y = F.linear(h, P[f"{prefix}.mlp.fc2.weight"], P[f"{prefix}.mlp.fc2.bias"])
+    return x + y if final_residual else y
 
 
 def mae2d_patchify(imgs, p):
@@ -201,7 +204,7 @@ def mae2d_patchify(imgs, p):
     return x.reshape(N, h * w, p * p * C)
 
 
-def mae2d_forward(P, imgs, cfg: MAE2DConfig, mask_ratio=0.75, noise=None):
+def mae2d_forward(P, imgs, cfg: MAE2DConfig, mask_ratio=0.75, noise=None, flash_compat=False):
     """OCTCube/models_mae.py:151-227 -> (loss, pred, mask, ids_restore)."""
     p = cfg.patch_size
     x = F.conv2d(imgs, P["patch_embed.proj.weight"], P["patch_embed.proj.bias"], stride=p).flatten(2).transpose(1, 2)
@@ -219,7 +222,7 @@ def mae2d_forward(P, imgs, cfg: MAE2DConfig, mask_ratio=0.75, noise=None):
     cls = (P["cls_token"] + P["pos_embed"][:, :1, :]).expand(N, -1, -1)
     x = torch.cat((cls, x), dim=1)
     for i in range(cfg.depth):
-        x = timm_block(x, P, f"blocks.{i}", cfg.num_heads, cfg.ln_eps)
+        x = timm_block(x, P, f"blocks.{i}", cfg.num_heads, cfg.ln_eps, not (flash_compat and i == cfg.depth - 1))
     x = F.layer_norm(x, (D,), P["norm.weight"], P["norm.bias"], cfg.ln_eps)
     x = F.linear(x, P["decoder_embed.weight"], P["decoder_embed.bias"])
     Dd = x.shape[-1]
@@ -228,7 +231,8 @@ def mae2d_forward(P, imgs, cfg: MAE2DConfig, mask_ratio=0.75, noise=None):
     x_ = torch.gather(x_, 1, ids_restore.unsqueeze(-1).expand(-1, -1, Dd))
     x = torch.cat([x[:, :1, :], x_], dim=1) + P["decoder_pos_embed"]
     for i in range(cfg.decoder_depth):
-        x = timm_block(x, P, f"decoder_blocks.{i}", cfg.decoder_num_heads, cfg.ln_eps)
+        x = timm_block(x, P, f"decoder_blocks.{i}", cfg.decoder_num_heads, cfg.ln_eps,
+                       not (flash_compat and i == cfg.decoder_depth - 1))
     x = F.layer_norm(x, (Dd,), P["decoder_norm.weight"], P["decoder_norm.bias"], cfg.ln_eps)
     pred = F.linear(x, P["decoder_pred.weight"], P["decoder_pred.bias"])[:, 1:, :]
     target = mae2d_patchify(imgs, p)

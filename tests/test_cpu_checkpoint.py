@@ -93,3 +93,58 @@ def test_flash_key_remap_matches_reference_and_round_trips(z):
     nat = C.to_native_layout(timm)
     assert torch.equal(nat["blocks.0.attn.k.weight"], timm["blocks.0.attn.qkv.weight"][4:8])
     assert torch.equal(nat["blocks.0.attn.v.bias"], timm["blocks.0.attn.qkv.bias"][8:])
+
+
+def test_retfound_rgb_2d_checkpoint_initialises_the_3d_mae_like_the_reference(golden_dir):
+    """a 2-D RGB (timm-layout) checkpoint -- RETFound / ImageNet -- must initialise the 3-D MAE exactly as the
+    reference's load_model_retfound[_flash_attn] does (Pre-training/custom_util/misc.py:489-533): the 3 RGB kernels become the
+    3 temporal taps (unsqueeze(1)), the embedding is mirrored into high_res_patch_embed, pos_embed is split into class +
+    bicubically resized spatial table, fused qkv is split.  Fixture: oracle/gen_golden_retfound.py (the reference's own
+    functions on a seeded synthetic checkpoint, loaded into the reference model)."""
+    import json
+    from functools import partial
+    from octcubem_amd import models_mae
+    from oracle import mae3d_ref as O
+    z = np.load(os.path.join(golden_dir, "retfound_init.npz"))
+    cfg = O.MAEConfig(**json.loads(str(z["cfg"])))
+    m = models_mae.MaskedAutoencoderViT(
+        input_size=cfg.input_size, patch_size=cfg.patch_size, in_chans=cfg.in_chans, embed_dim=cfg.embed_dim, depth=cfg.depth,
+        num_heads=cfg.num_heads, decoder_embed_dim=cfg.decoder_embed_dim, decoder_depth=cfg.decoder_depth,
+        decoder_num_heads=cfg.decoder_num_heads, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_frames=cfg.num_frames,
+        t_patch_size=cfg.t_patch_size, sep_pos_embed=True, cls_embed=True, pred_t_dim=cfg.pred_t_dim,
+        high_res_input_size=cfg.high_res_input_size)
+    m.load_state_dict(O.init_params(cfg, seed=int(z["param_seed"]), bias_std=float(z["param_bias_std"])), strict=True)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    # the synthetic checkpoint, re-drawn exactly as the generator drew it
+    g = torch.Generator().manual_seed(int(z["ckpt_seed"]))
+    shapes = {"cls_token": (1, 1, 128), "pos_embed": (1, 197, 128), "patch_embed.proj.weight": (128, 3, 16, 16),
+              "patch_embed.proj.bias": (128,), "norm.weight": (128,), "norm.bias": (128,), "decoder_embed.weight": (64, 128),
+              "decoder_embed.bias": (64,), "mask_token": (1, 1, 64)}
+    ck = {k: torch.randn(s, generator=g) for k, s in shapes.items()}
+    for pre, n, d in (("blocks", 2, 128), ("decoder_blocks", 2, 64)):
+        for i in range(n):
+            ck[f"{pre}.{i}.attn.qkv.weight"] = torch.randn(3 * d, d, generator=g)
+            ck[f"{pre}.{i}.attn.qkv.bias"] = torch.randn(3 * d, generator=g)
+            ck[f"{pre}.{i}.attn.proj.weight"] = torch.randn(d, d, generator=g)
+            ck[f"{pre}.{i}.attn.proj.bias"] = torch.randn(d, generator=g)
+            for nm in ("norm1", "norm2"):
+                ck[f"{pre}.{i}.{nm}.weight"] = torch.randn(d, generator=g); ck[f"{pre}.{i}.{nm}.bias"] = torch.randn(d, generator=g)
+            ck[f"{pre}.{i}.mlp.fc1.weight"] = torch.randn(4 * d, d, generator=g); ck[f"{pre}.{i}.mlp.fc1.bias"] = torch.randn(4 * d, generator=g)
+            ck[f"{pre}.{i}.mlp.fc2.weight"] = torch.randn(d, 4 * d, generator=g); ck[f"{pre}.{i}.mlp.fc2.bias"] = torch.randn(d, generator=g)
+    assert list(ck.keys()) == json.loads(str(z["ckpt_keys"]))
+    missing, unexpected = C.load_pretrained(m, {"model": ck})
+    assert sorted(missing) == json.loads(str(z["missing"])) and sorted(unexpected) == json.loads(str(z["unexpected"]))
+    after = m.state_dict()
+    changed = sorted(k for k in after if not torch.equal(after[k], before[k]))
+    assert changed == json.loads(str(z["changed"]))
+    sums = np.array([[float(after[k].double().sum()), float((after[k].double() ** 2).sum())] for k in changed])
+    assert np.allclose(sums, z["after_sums"], rtol=1e-6, atol=1e-6)
+    for key in z.files:
+        if key.startswith("after/"):
+            k = key[6:]
+            v = after[k].flatten()
+            v = v if v.numel() <= 8192 else v[::13]
+            assert torch.equal(v, torch.from_numpy(z[key])), k            # same ATen calls on the same numbers: bit-exact
+    # the three RGB kernels are the three temporal taps, and the 512^2 branch starts from the same embedding
+    assert torch.equal(after["patch_embed.proj.weight"][:, 0], ck["patch_embed.proj.weight"])
+    assert torch.equal(after["high_res_patch_embed.proj.weight"], after["patch_embed.proj.weight"])

@@ -40,6 +40,39 @@ def towers():
     return c3, c2, P3, P2, m3.to(DEV), m2.to(DEV)
 
 
+def test_vit2d_tower_vs_reference_golden(golden_dir):
+    """models_vit.VisionTransformer (the en-face tower) against the fixture produced by the reference's OCTCube/models_vit.py
+    subclass on a restated timm base (oracle/gen_golden_vit2d.py): output, loss, gradients; both pooling variants."""
+    import json, os
+    import numpy as np
+    from functools import partial
+    z = np.load(os.path.join(golden_dir, "vit2d_small.npz"))
+    x, tgt = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["target"]).to(DEV)
+    for tag in ("gp1", "gp0"):
+        cfg = V.ViT2DConfig(**json.loads(str(z[f"{tag}/cfg"])))
+        P = V.init_from_shapes(V.vit2d_param_shapes(cfg), seed=int(z["param_seed"]))
+        m = models_vit.VisionTransformer(img_size=cfg.img_size, patch_size=cfg.patch_size, in_chans=cfg.in_chans,
+                                         num_classes=cfg.num_classes, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
+                                         mlp_ratio=4, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
+                                         global_pool=cfg.global_pool)
+        assert set(m.state_dict()) == set(P)
+        m.load_state_dict(P, strict=True)
+        m = m.to(DEV).eval()
+        out = m(x)
+        assert rel(out, z[f"{tag}/out"]) <= 1e-2
+        loss = torch.nn.functional.cross_entropy(out.float(), tgt)
+        assert abs(float(loss) - float(z[f"{tag}/loss"])) <= 1e-2 * float(z[f"{tag}/loss"])
+        loss.backward()
+        total = float(np.sqrt(sum(float(z[k]) ** 2 for k in z.files if k.startswith(f"{tag}/gnorm/"))))
+        for k, p in m.named_parameters():
+            gn = float(z[f"{tag}/gnorm/{k}"])
+            if gn < 1e-3 * total:
+                continue
+            ref = torch.from_numpy(z[f"{tag}/grad/{k}"])
+            mine = p.grad.cpu() if p.grad.numel() <= 4096 else p.grad.cpu().flatten()[::11]
+            assert rel(mine.reshape(ref.shape), ref) <= 5e-2, (tag, k, rel(mine.reshape(ref.shape), ref))
+
+
 def test_vit2d_tower_matches_oracle():
     _, c2, _, P2, _, m2 = towers()
     x = torch.randn(3, 3, 64, 64, generator=torch.Generator().manual_seed(1))
@@ -92,3 +125,31 @@ def test_coem_contrastive_step_matches_oracle():
         model.logit_scale.fill_(10.0)
     coem.clamp_logit_scale(model)
     assert abs(float(model.logit_scale) - math.log(100)) < 1e-6
+
+
+def test_coem_step_with_reducers_exchanges_both_towers():
+    """the data-parallel COEM step must exchange the towers' weight gradients (one FlatGradReducer per tower
+    arena) and the temperature's.  With a ONE-RANK RCCL communicator (force=True) the exchanged step must equal the local one,
+    every byte of both arenas must have gone through the communicator, and the feature all-gather takes the native path."""
+    from octcubem_amd import comm as ocomm
+    c3, c2, P3, P2, m3, m2 = towers()
+    model = coem.CustomTextCLIP(m3, m2).to(DEV).train()
+    g = torch.Generator().manual_seed(5)
+    vol = torch.rand(4, 1, 6, 64, 64, generator=g).to(DEV); ir = torch.randn(4, 3, 64, 64, generator=g).to(DEV)
+    opts = [foptim.FusedAdamW(m3.parameters(), lr=0.0), foptim.FusedAdamW(m2.parameters(), lr=0.0),
+            torch.optim.SGD([model.logit_scale], lr=0.0)]
+    l0 = coem.train_step(model, coem.ClipLoss(), vol, ir, opts)
+    torch.cuda.synchronize()
+    g3, g2, gl = m3.arena.grad.clone(), m2.arena.grad.clone(), model.logit_scale.grad.clone()
+    comm1 = ocomm.NativeComm(ocomm.NativeComm.unique_id(), 0, 1, 0)
+    try:
+        reds = coem.make_reducers(model, comm=comm1, force=True, n_chunks=3)
+        l1 = coem.train_step(model, coem.ClipLoss(), vol, ir, opts, reducers=reds)
+        torch.cuda.synchronize()
+        assert abs(float(l1) - float(l0)) <= 1e-6 * abs(float(l0))
+        for a, b in ((m3.arena.grad, g3), (m2.arena.grad, g2)):
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7
+        assert torch.equal(model.logit_scale.grad, gl)
+        assert reds[0].stats["bytes_total"] == 4 * m3.arena.total and reds[1].stats["bytes_total"] == 4 * m2.arena.total
+    finally:
+        comm1.destroy()

@@ -488,6 +488,50 @@ def test_fused_adamw_and_grad_norm_match_oracle(golden_dir):
     assert abs(float(coef) - min(1.0, 0.5 / (float(norm) + 1e-6))) < 1e-6
 
 
+def test_fused_adamw_resumes_from_its_own_and_from_a_torch_adamw_state():
+    """after load_state_dict the kernel must update the LOADED moment buffers (the device pointer table is keyed
+    on them too), and a torch.optim.AdamW state (per-parameter "step", no group "_step") must continue its bias correction."""
+    g = torch.Generator().manual_seed(11)
+    shapes = [(64, 32), (5,), (3000,)]
+    grads = [[torch.randn(s, generator=g) for s in shapes] for _ in range(6)]
+    init = [torch.randn(s, generator=g) for s in shapes]
+
+    def fresh():
+        return [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+
+    def run(opt, ps, steps):
+        for k in steps:
+            for p, gr in zip(ps, grads[k]):
+                p.grad = gr.to(DEV)
+            opt.step()
+
+    kw = dict(lr=1e-2, betas=(0.9, 0.95), weight_decay=0.05)
+    ref_ps = fresh(); ref = torch.optim.AdamW(ref_ps, **kw)                 # the optimizer the reference driver builds
+    run(ref, ref_ps, range(6))
+    # (a) own checkpoint: 3 steps, save, step once more (so that the saved tables are stale), load, 3 steps
+    ps = fresh(); opt = foptim.FusedAdamW(ps, **kw)
+    run(opt, ps, range(3))
+    sd = {k: (v if not isinstance(v, dict) else v) for k, v in opt.state_dict().items()}
+    import copy
+    sd = copy.deepcopy(sd); w = [p.detach().clone() for p in ps]
+    run(opt, ps, [3])
+    with torch.no_grad():
+        for p, t in zip(ps, w):
+            p.copy_(t)
+    opt.load_state_dict(sd)
+    run(opt, ps, range(3, 6))
+    for p, r in zip(ps, ref_ps):
+        assert rel(p.detach(), r.detach()) < 1e-5
+    # (b) a torch.optim.AdamW state after 3 steps, continued by FusedAdamW
+    t_ps = fresh(); t_opt = torch.optim.AdamW(t_ps, **kw)
+    run(t_opt, t_ps, range(3))
+    ps2 = [torch.nn.Parameter(p.detach().clone()) for p in t_ps]; opt2 = foptim.FusedAdamW(ps2, **kw)
+    opt2.load_state_dict(copy.deepcopy(t_opt.state_dict()))
+    run(opt2, ps2, range(3, 6))
+    for p, r in zip(ps2, ref_ps):
+        assert rel(p.detach(), r.detach()) < 1e-5
+
+
 @pytest.mark.parametrize("HD", [64, 32])
 @pytest.mark.parametrize("kind", ["overflow", "underflow"])
 def test_attention_optimistic_forward_falls_back(HD, kind):

@@ -93,6 +93,46 @@ def test_mae2d_vs_reference_golden(golden_dir):
     assert m.pos_embed.grad is None and m.decoder_pos_embed.grad is None            # fixed sin-cos tables
 
 
+def test_mae2d_flash_twin(golden_dir):
+    """The 2-D flash MAE (OCTCube/models_mae_flash_attn.py:70-176): use_flash_attn=True builds create_block blocks (keys
+    blocks.i.mixer.Wqkv / out_proj) and runs the ``x, residual = blk(x, residual)`` loop, whose output is the stream WITHOUT
+    the last block's residual; flash_compat=True is the same computation on the timm key layout.
+    Both against the oracle's restatement of that semantics (flash-attn cannot run here: parity unpinned beyond it)."""
+    from octcubem_amd import checkpoint as CK
+    z = np.load(os.path.join(golden_dir, "mae2d_small.npz"))
+    cfg = V.MAE2DConfig(**json.loads(str(z["cfg"])))
+    P = V.mae2d_init(cfg, seed=int(z["param_seed"]))
+    imgs, noise = torch.from_numpy(z["imgs"]), torch.from_numpy(z["noise"])
+    with torch.no_grad():
+        loss_f, pred_f, mask_f, _ = V.mae2d_forward(P, imgs, cfg, 0.75, noise, flash_compat=True)
+        loss_s, pred_s, _, _ = V.mae2d_forward(P, imgs, cfg, 0.75, noise)
+    assert rel(pred_f, pred_s) > 5e-2                                   # the two semantics really differ
+    kw = dict(patch_size=cfg.patch_size, in_chans=cfg.in_chans, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
+              decoder_embed_dim=cfg.decoder_embed_dim, decoder_depth=cfg.decoder_depth, decoder_num_heads=cfg.decoder_num_heads,
+              mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6))
+    m = models_mae_2d.MaskedAutoencoderViT(img_size=cfg.img_size, flash_compat=True, **kw)
+    m.load_state_dict(P, strict=True)
+    m = m.to(DEV)
+    with torch.no_grad():
+        loss, pred, mask = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
+    assert torch.equal(mask.cpu(), mask_f) and abs(float(loss) - float(loss_f)) <= 2e-3 * float(loss_f) and rel(pred, pred_f) <= 1e-2
+    mf = models_mae_2d.MaskedAutoencoderViT(input_size=cfg.img_size, use_flash_attn=True, **kw)      # the flash file's argument name
+    keys = set(mf.state_dict())
+    assert "blocks.0.mixer.Wqkv.weight" in keys and "decoder_blocks.1.mixer.out_proj.bias" in keys and "blocks.0.attn.qkv.weight" not in keys
+    assert mf.patch_embed.input_size == (cfg.img_size, cfg.img_size)
+    Pf = {}
+    for k, v in P.items():
+        k2 = k.replace(".attn.qkv.", ".mixer.Wqkv.").replace(".attn.proj.", ".mixer.out_proj.")
+        Pf[k2] = v
+    assert set(Pf) == keys
+    mf.load_state_dict(Pf, strict=True)
+    mf = mf.to(DEV)
+    lossf, predf, maskf = mf(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
+    lossf.backward()
+    assert torch.equal(maskf.cpu(), mask_f) and abs(float(lossf) - float(loss_f)) <= 2e-3 * float(loss_f) and rel(predf, pred_f) <= 1e-2
+    assert all(torch.isfinite(p.grad).all() for p in mf.parameters() if p.grad is not None)
+
+
 def test_config1_vitb_2d_mae_full_size_vs_oracle():
     """BASELINE config 1: ViT-B MAE forward + loss on 2 x 3 x 256 x 256 random B-scans, HIP path vs the CPU oracle."""
     cfg = V.MAE2DConfig(img_size=256, embed_dim=768, depth=12, num_heads=12, decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16)
@@ -114,8 +154,7 @@ def test_config1_vitb_2d_mae_full_size_vs_oracle():
 def test_vit_st_flash_compat_and_2d_checkpoint_inflation():
     """(1) flash_compat on the fine-tune ViT: last block returns its MLP branch only (oracle restatement).
     (2) checkpoint.load_pretrained from a timm-layout 2-D ViT (fused qkv, Conv2d RGB patch embedding, 1 + 14x14 pos_embed): keys
-    split, patch embedding summed over RGB and inflated over t_patch_size (mean-preserving), pos_embed -> class + resized
-    spatial table; the model then matches the oracle fed the converted tensors."""
+    split, the RGB kernels of the patch embedding become the temporal taps, pos_embed -> class + resized spatial table; the model then matches the oracle fed the converted tensors."""
     from octcubem_amd import checkpoint as CK
     cfg = V.ViTSTConfig(num_frames=6, t_patch_size=3, img_size=64, patch_size=16, in_chans=1, num_classes=8, embed_dim=128, depth=2,
                         num_heads=2, global_pool=True)
@@ -147,7 +186,9 @@ def test_vit_st_flash_compat_and_2d_checkpoint_inflation():
     missing, unexpected = CK.load_pretrained(m2, ck)
     assert not unexpected and sorted(missing) == ["head.bias", "head.weight", "pos_embed_temporal"]
     P2 = dict(P)
-    P2["patch_embed.proj.weight"] = ck["patch_embed.proj.weight"].sum(1, keepdim=True).unsqueeze(2).repeat(1, 1, 3, 1, 1) / 3
+    # 3 RGB kernels -> the 3 temporal taps of the single-channel kernel (the reference's convert_patchembed_2Dto3D = unsqueeze(1),
+    # Pre-training/custom_util/misc.py:1326-1329; pinned by tests/test_cpu_checkpoint.py against the reference itself)
+    P2["patch_embed.proj.weight"] = ck["patch_embed.proj.weight"].unsqueeze(1)
     P2["pos_embed_class"] = ck["pos_embed"][:, :1]
     P2["pos_embed_spatial"] = torch.nn.functional.interpolate(ck["pos_embed"][:, 1:].reshape(1, 14, 14, 128).permute(0, 3, 1, 2), size=(4, 4),
                                                                mode="bicubic", align_corners=False).permute(0, 2, 3, 1).flatten(1, 2)

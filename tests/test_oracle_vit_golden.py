@@ -58,3 +58,26 @@ def test_mae2d_forward_backward_matches_reference(golden_dir):
         ref = torch.from_numpy(z[f"grad/{k}"])
         mine = g if g.numel() <= 8192 else g.flatten()[::7]
         assert relerr(mine.reshape(ref.shape), ref) <= 5e-5, k
+
+
+def test_vit2d_tower_matches_reference_subclass(golden_dir):
+    """The COEM en-face tower: oracle vit2d_forward against the reference's OCTCube/models_vit.py VisionTransformer run on a
+    restated timm 0.3.2 base class (oracle/gen_golden_vit2d.py) -- global-pool + fc_norm and cls + norm variants."""
+    z = np.load(os.path.join(golden_dir, "vit2d_small.npz"))
+    x, tgt = torch.from_numpy(z["x"]), torch.from_numpy(z["target"])
+    for tag in ("gp1", "gp0"):
+        cfg = V.ViT2DConfig(**json.loads(str(z[f"{tag}/cfg"])))
+        P = V.init_from_shapes(V.vit2d_param_shapes(cfg), seed=int(z["param_seed"]))
+        Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        out = V.vit2d_forward(Pg, x, cfg)
+        assert relerr(out, z[f"{tag}/out"]) <= 1e-5
+        loss = torch.nn.functional.cross_entropy(out, tgt)
+        assert abs(float(loss) - float(z[f"{tag}/loss"])) <= 1e-5 * float(z[f"{tag}/loss"])
+        loss.backward()
+        for k, v in Pg.items():
+            gn = float(z[f"{tag}/gnorm/{k}"])
+            if gn < 1e-7:
+                continue
+            ref = torch.from_numpy(z[f"{tag}/grad/{k}"])
+            mine = v.grad if v.grad.numel() <= 4096 else v.grad.flatten()[::11]
+            assert relerr(mine.reshape(ref.shape), ref) <= 5e-5, (tag, k)
