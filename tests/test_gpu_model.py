@@ -2,9 +2,12 @@
   (1) the golden vectors produced by the REAL reference (tests/golden/mae3d_small*.npz), and
   (2) the CPU oracle on the same seeded inputs, up to the full ViT-L / 60x256x256 configuration.
 
-Tolerances (bf16 MFMA operands, fp32 accumulation / residual stream / statistics; BASELINE's target is 1e-3 rel on
-the loss): loss rel <= 1e-3 (small model) ; pred rel-L2 <= 1e-2 ; gradient rel-L2 per tensor <= 5e-2 with the
-global gradient norm within 1e-2 ; masking indices bit-exact.
+Bounds (bf16 MFMA operands, fp32 accumulation / residual stream / statistics) are the errors MEASURED on MI355X in round 2
+x ~1.5, each through tests.conftest.parity (recorded to gpurun_out/parity_measured.json; table in DESIGN.md section 2):
+loss-level quantities 1e-4 ... 4e-4 (the north star's 1e-3 with margin), pred rel-L2 <= 9.7e-3, per-tensor gradient rel-L2
+<= 3e-2 (median 1.2e-2), global gradient norm <= 1.5e-3; masking indices bit-exact.  Where the element-wise 5e-3 ... 2e-2 comes
+from is shown in tests/test_gpu_rounding_model.py: the same computation with bf16 rounding at the HIP path's rounding points
+reproduces the HIP results to <= 1e-3.
 """
 import json
 import os
@@ -18,6 +21,7 @@ pytestmark = pytest.mark.gpu
 if torch.cuda.is_available():
     from octcubem_amd import models_mae, misc, optim as foptim, lr_sched, engine_pretrain
 from oracle import mae3d_ref as O
+from tests.conftest import parity
 
 DEV = "cuda"
 
@@ -67,9 +71,10 @@ def test_small_model_vs_reference_golden(golden_dir):
     torch.cuda.synchronize()
     assert torch.equal(mask.cpu(), torch.from_numpy(z["mask"]))                       # bit-exact
     assert torch.equal(m._ids_restore.cpu(), torch.from_numpy(z["ids_restore"]))      # bit-exact
-    assert abs(float(loss) - float(z["loss"])) <= 1e-3 * float(z["loss"])
-    assert rel(pred, z["pred"]) <= 1e-2
-    assert rel(fl, z["frame_losses"]) <= 2e-3
+    parity("small/loss", abs(float(loss) - float(z["loss"])) / float(z["loss"]), 2e-4)          # measured 6.8e-5 (r02)
+    parity("small/pred", rel(pred, z["pred"]), 9.5e-3)                                          # measured 6.2e-3: bf16 operand rounding, see test_gpu_rounding_model.py
+    parity("small/frame_losses", rel(fl, z["frame_losses"]), 3e-4)                             # measured 1.9e-4
+    worst_g = 0.0
     total_ref = float(np.sqrt(sum(float(z[k]) ** 2 for k in z.files if k.startswith("gnorm/"))))
     sq = 0.0
     for k, p in m.named_parameters():
@@ -86,8 +91,12 @@ def test_small_model_vs_reference_golden(golden_dir):
             continue
         ref = torch.from_numpy(z[f"grad/{k}"])
         mine = g.cpu() if g.numel() <= 8192 else g.cpu().flatten()[::7]
-        assert rel(mine.reshape(ref.shape), ref) <= 5e-2, (k, rel(mine.reshape(ref.shape), ref))
-    assert abs(sq ** 0.5 - total_ref) <= 1e-2 * total_ref
+        if gn >= 1e-3 * total_ref:
+            worst_g = max(worst_g, rel(mine.reshape(ref.shape), ref))
+        else:                                    # tensors far below the global norm: absolute, against the global norm
+            assert float((mine.reshape(ref.shape).double() - ref.double()).norm()) <= 2e-3 * total_ref, k
+    parity("small/worst_grad", worst_g, 3e-2)                                                   # measured 2.0e-2
+    parity("small/grad_norm", abs(sq ** 0.5 - total_ref) / total_ref, 1e-3)                      # measured 3.3e-4
 
 
 def test_small_model_variants_vs_reference_golden(golden_dir):
@@ -98,15 +107,15 @@ def test_small_model_variants_vs_reference_golden(golden_dir):
     with torch.no_grad():
         loss, pred, mask = m(imgs, mask_ratio=0.9, noise=noise)
     assert torch.equal(mask.cpu(), torch.from_numpy(v["mask_r90"]))
-    assert abs(float(loss) - float(v["loss_normpix_r90"])) <= 1e-3 * float(v["loss_normpix_r90"])
-    assert rel(pred, v["pred_r90"]) <= 1e-2
+    parity("variants/loss_normpix_r90", abs(float(loss) - float(v["loss_normpix_r90"])) / float(v["loss_normpix_r90"]), 1e-4)   # measured 2.4e-5
+    parity("variants/pred_r90", rel(pred, v["pred_r90"]), 8.5e-3)                                # measured 5.5e-3
     # high-res (2-D / 512-style) branch through high_res_patch_embed, un-interpolated spatial table, no temporal table
     m2 = build(cfg, P)
     with torch.no_grad():
         loss, pred, mask = m2(torch.from_numpy(v["imgs_hr"]).to(DEV), mask_ratio=0.75, noise=torch.from_numpy(v["noise_hr"]).to(DEV))
     assert torch.equal(mask.cpu(), torch.from_numpy(v["mask_hr"]))
-    assert abs(float(loss) - float(v["loss_hr"])) <= 1e-3 * float(v["loss_hr"])
-    assert rel(pred, v["pred_hr"]) <= 1e-2
+    parity("variants/loss_hr", abs(float(loss) - float(v["loss_hr"])) / float(v["loss_hr"]), 3e-4)   # measured 1.7e-4
+    parity("variants/pred_hr", rel(pred, v["pred_hr"]), 9.7e-3)                                  # measured 6.5e-3
 
 
 def test_mid_model_vs_oracle_seeded():
@@ -121,18 +130,21 @@ def test_mid_model_vs_oracle_seeded():
     loss, pred, mask = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
     loss.backward()
     assert torch.equal(mask.cpu(), mask_r) and torch.equal(m._ids_restore.cpu(), ids_r)
-    assert abs(float(loss) - float(loss_r)) <= 1e-3 * float(loss_r)
-    assert rel(pred, pred_r) <= 1e-2
+    parity("mid/loss", abs(float(loss) - float(loss_r)) / float(loss_r), 2e-4)                    # measured 8.2e-5
+    parity("mid/pred", rel(pred, pred_r), 9.7e-3)                                                 # measured 6.5e-3
     total = float(O.grad_norm(grads_r.values()))
     errs = {}
     for k, p in m.named_parameters():
         gr = grads_r[k]
         if float(gr.norm()) < 1e-6 * total:          # exactly-zero (unused) or mathematically-zero (attn.k.bias) gradients
             assert p.grad is None or float(p.grad.double().norm()) <= 1e-4 * total, k
+        elif float(gr.norm()) < 1e-3 * total:         # far below the global norm: absolute, against the global norm
+            assert float((p.grad.cpu().double() - gr.double()).norm()) <= 2e-3 * total, k
         else:
             errs[k] = rel(p.grad, gr)
     worst = max((v, k) for k, v in errs.items())
-    assert worst[0] <= 5e-2, worst
+    parity("mid/worst_grad", worst[0], 3e-2)                                                      # measured 2.0e-2
+    parity("mid/median_grad", sorted(errs.values())[len(errs) // 2], 1.2e-2)                      # measured 8.1e-3
     print("mid model: loss rel %.2e pred rel %.2e worst grad rel %.2e (%s) median %.2e" % (
         abs(float(loss) - float(loss_r)) / float(loss_r), rel(pred, pred_r), worst[0], worst[1], sorted(errs.values())[len(errs) // 2]))
 
@@ -162,8 +174,8 @@ def test_train_step_matches_oracle_adamw():
         loss, _, _ = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
         norm = scaler(loss, opt, parameters=m.parameters(), clip_grad=None)
         loss_r, _, _, _, G = O.forward_backward(Pr, imgs, cfg, 0.75, noise)
-        assert abs(float(loss) - float(loss_r)) <= 2e-3 * float(loss_r)
-        assert abs(float(norm) - float(O.grad_norm(G.values()))) <= 2e-2 * float(O.grad_norm(G.values()))
+        parity(f"train_step/loss{step}", abs(float(loss) - float(loss_r)) / float(loss_r), 1e-4)      # measured 5.2e-5
+        parity(f"train_step/grad_norm{step}", abs(float(norm) - float(O.grad_norm(G.values()))) / float(O.grad_norm(G.values())), 1.5e-3)   # measured 1.0e-3
         assert abs(lr - O.cosine_lr(0.5 * step, 1e-3, 0.0, 1, 10)) < 1e-12
         for k in Pr:
             Pr[k], Mr[k], Vr[k] = O.adamw_step(Pr[k], G[k], Mr[k], Vr[k], step, lr, 0.9, 0.95, 1e-8, 0.0 if k in nd else 0.05)
@@ -174,7 +186,7 @@ def test_train_step_matches_oracle_adamw():
     dot = sum(float(((sd[k].cpu().double() - P[k].double()) * (Pr[k].double() - P[k].double())).sum()) for k in Pr)
     n1 = sum(float((sd[k].cpu().double() - P[k].double()).pow(2).sum()) for k in Pr) ** 0.5
     n2 = sum(float((Pr[k].double() - P[k].double()).pow(2).sum()) for k in Pr) ** 0.5
-    assert dot / (n1 * n2) >= 0.85, dot / (n1 * n2)
+    parity("train_step/1-cos(update)", 1.0 - dot / (n1 * n2), 3e-3)                               # measured 1.4e-3
 
 
 def test_engine_train_one_epoch_runs_and_learns():
@@ -211,10 +223,10 @@ def test_vitl_full_size_forward_vs_reference_pins(golden_dir):
         loss, pred, mask = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
     assert torch.equal(m._ids_restore.cpu().int(), torch.from_numpy(pins["ids_restore"]))      # bit-exact at L = 5120
     assert float(mask.sum()) == 3840.0
-    assert abs(float(loss) - float(pins["loss"])) <= 1e-3 * float(pins["loss"])
+    parity("vitl/loss", abs(float(loss) - float(pins["loss"])) / float(pins["loss"]), 4e-4)              # measured 2.1e-4
     samp = pred.flatten()[torch.from_numpy(pins["pred_idx"]).to(DEV)]
-    assert rel(samp, pins["pred_samples"]) <= 2e-2
-    assert abs(float(pred.double().norm()) - float(pins["pred_l2"])) <= 1e-2 * float(pins["pred_l2"])
+    parity("vitl/pred_samples", rel(samp, pins["pred_samples"]), 1.2e-2)                          # measured 8.0e-3
+    parity("vitl/pred_l2", abs(float(pred.double().norm()) - float(pins["pred_l2"])) / float(pins["pred_l2"]), 3e-4)   # measured 1.3e-4
 
 
 def test_full_size_properties_batch2():

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 if torch.cuda.is_available():
     from octcubem_amd import models_vit_st, models_mae_2d
 from oracle import vit_ref as V
+from tests.conftest import parity
 
 DEV = "cuda"
 
@@ -24,8 +25,9 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def check_grads(model, z, tol=5e-2):
+def check_grads(model, z, tol=5e-2, label="grads"):
     total = float(np.sqrt(sum(float(z[k]) ** 2 for k in z.files if k.startswith("gnorm/"))))
+    worst = 0.0
     for k, p in model.named_parameters():
         if f"gnorm/{k}" not in z.files:
             continue
@@ -36,7 +38,11 @@ def check_grads(model, z, tol=5e-2):
             continue
         ref = torch.from_numpy(z[f"grad/{k}"])
         mine = g.cpu() if g.numel() <= 8192 else g.cpu().flatten()[::7]
-        assert rel(mine.reshape(ref.shape), ref) <= tol, (k, rel(mine.reshape(ref.shape), ref))
+        if gn < 1e-3 * total:                     # far below the global norm: absolute, against the global norm
+            assert float((mine.reshape(ref.shape).double() - ref.double()).norm()) <= 2e-3 * total, k
+            continue
+        worst = max(worst, rel(mine.reshape(ref.shape), ref))
+    parity(f"{label}/worst_grad", worst, tol)
 
 
 def test_vit_st_vs_reference_golden(golden_dir):
@@ -52,14 +58,14 @@ def test_vit_st_vs_reference_golden(golden_dir):
     m = m.to(DEV).eval()
     x = torch.from_numpy(z["x"]).to(DEV)
     logits, emb = m(x, return_embeddings=True)
-    assert rel(logits, z["logits"]) <= 1e-2 and rel(emb, z["embedding"]) <= 1e-2
+    parity("vit_st_small/logits", rel(logits, z["logits"]), 7.5e-3); parity("vit_st_small/embedding", rel(emb, z["embedding"]), 5.5e-3)   # measured 4.9e-3 / 3.6e-3
     loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(z["target"]).to(DEV))
     # cross-entropy moves by at most 2 x the largest logit error; the logits themselves are held to 1e-2 rel-L2 above
     dl = float((logits.detach().cpu() - torch.from_numpy(z["logits"])).abs().max())
     assert abs(float(loss) - float(z["loss"])) <= 2 * dl + 1e-6, (float(loss), float(z["loss"]), dl)
-    assert abs(float(loss) - float(z["loss"])) <= 1e-2 * float(z["loss"])
+    parity("vit_st_small/loss", abs(float(loss) - float(z["loss"])) / float(z["loss"]), 4.5e-3)   # measured 2.8e-3 (cross-entropy of 8 logits)
     loss.backward()
-    check_grads(m, z)
+    check_grads(m, z, tol=2.5e-2, label="vit_st_small")                                           # measured 1.6e-2
     assert m.norm.weight.grad is None or float(m.norm.weight.grad.abs().max()) == 0.0      # computed-but-unused norm
     m2 = models_vit_st.VisionTransformer(global_pool=False, **kw)
     m2.load_state_dict(P, strict=True)
@@ -87,9 +93,9 @@ def test_mae2d_vs_reference_golden(golden_dir):
     loss, pred, mask = m(imgs, mask_ratio=0.75, noise=noise)
     loss.backward()
     assert torch.equal(mask.cpu(), torch.from_numpy(z["mask"])) and torch.equal(m._ids_restore.cpu(), torch.from_numpy(z["ids_restore"]))
-    assert abs(float(loss) - float(z["loss"])) <= 2e-3 * float(z["loss"])
-    assert rel(pred, z["pred"]) <= 1e-2
-    check_grads(m, z)
+    parity("mae2d_small/loss", abs(float(loss) - float(z["loss"])) / float(z["loss"]), 1e-4)      # measured 2.4e-5
+    parity("mae2d_small/pred", rel(pred, z["pred"]), 8e-3)                                        # measured 5.2e-3
+    check_grads(m, z, tol=1.4e-2, label="mae2d_small")                                            # measured 9.3e-3
     assert m.pos_embed.grad is None and m.decoder_pos_embed.grad is None            # fixed sin-cos tables
 
 
@@ -147,8 +153,8 @@ def test_config1_vitb_2d_mae_full_size_vs_oracle():
     with torch.no_grad():
         loss, pred, mask = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
     assert torch.equal(mask.cpu(), mask_r) and torch.equal(m._ids_restore.cpu(), ids_r)
-    assert abs(float(loss) - float(loss_r)) <= 1e-3 * float(loss_r)
-    assert rel(pred, pred_r) <= 1e-2
+    parity("config1_vitb/loss", abs(float(loss) - float(loss_r)) / float(loss_r), 1.5e-4)          # measured 7.1e-5
+    parity("config1_vitb/pred", rel(pred, pred_r), 9e-3)                                          # measured 5.9e-3
 
 
 def test_vit_st_flash_compat_and_2d_checkpoint_inflation():
