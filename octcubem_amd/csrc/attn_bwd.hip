@@ -35,25 +35,6 @@ __device__ __forceinline__ f32x4_t mfma16(bf16x8 a, bf16x8 b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-#ifndef BWD_PIPE
-#define BWD_PIPE 0      // 0: plain unit loop (fastest measured); 2: three units in flight with sched_group_barrier interleave
-#endif
-#ifndef BWD_PRIO
-#define BWD_PRIO 0      // 1: static priority for waves 4-7 (swaps which half waits at the barrier; no net gain)
-#endif
-#ifndef BWD_P2_PRELOAD
-#define BWD_P2_PRELOAD 0
-#endif
-#ifndef BWD_KT_REGS
-#define BWD_KT_REGS 1   // K^T fragments of the dQ product in registers (plain form only: the pipelined form needs the registers)
-#endif
-#ifndef BWD_SB
-#define BWD_SB 1
-#endif
-#ifndef BWD_STAGGER
-#define BWD_STAGGER 0
-#endif
-
 #ifdef BWD_STAMP
 // diagnostic build only: per-wave cycle sums of the tile loop's segments (never read by the kernel itself)
 __device__ unsigned long long g_bwd_stamp[512 * 8 * 8];
@@ -86,23 +67,26 @@ struct BwdCfg {
   static constexpr int KH = PAIR ? KB / 2 : KB;         // keys one wave covers in the dQ product
   static constexpr int QSTEPS = KH / 32;                // 16x16x32 k-steps per output tile
   static constexpr int NT = PAIR ? 1 : 2;               // dQ output tiles a wave read-modify-writes per query tile
+  static constexpr int NIMG = 1;                        // dS images
   using T = Tile<HD>;
   static constexpr int PD = 2 * T::BYTES / 1024 / NW;   // LDS-DMA data pieces per wave per tile (Q and dO together)
   static_assert(PD >= 1 && PD * NW * 1024 == 2 * T::BYTES, "tile pieces must divide over the waves");
-  // LDS map
-  // (the rings come first: their fragment reads then reach everything from one base register through the 16-bit offset field)
+  // LDS map (the rings come first: their fragment reads reach everything from one base register through the offset field)
   static constexpr int QR = 0;                          // Q ring
   static constexpr int OR_ = QR + NB * T::BYTES;        // dO ring
   static constexpr int CR = OR_ + NB * T::BYTES;        // constants ring: [NB][2][64] f32
-  static constexpr int XCH = CR + NB * 512;             // pair exchange: [NW][64 lanes][4] f32
-  static constexpr int OLD = XCH + NW * 1024;           // workspace values of the tile in flight: [NW][NT][64 lanes][4] f32
-  static constexpr int IMG = OLD + NW * NT * 1024;      // dS image [KB keys][64 queries] bf16
-  static constexpr int IMG_BYTES = KB * 128;
-  static constexpr int KST = IMG + IMG_BYTES;           // this block's K rows [KB][HD] bf16 (swizzled 8-byte chunks), read
-  static constexpr int KST_BYTES = KB * HD * 2;         //   transposed as the A operand of the dQ product
-  static constexpr int LDS = KST + KST_BYTES;
+  // pair exchange [NW][64 lanes] f32x4
+  static constexpr int XCH = CR + NB * 512;
+  static constexpr int XCH_BYTES = PAIR ? NW * 1024 : 0;
+  // workspace values of the tile in flight, brought in by LDS-DMA: [NW][NT][64 lanes] f32x4
+  static constexpr int OLD = XCH + XCH_BYTES;
+  static constexpr int OLD_BYTES = NW * NT * 1024;
+  static constexpr int IMG = OLD + OLD_BYTES;           // dS image(s) [KB keys][64 queries] bf16; image 0 also stages the
+  static constexpr int IMG_BYTES = KB * 128;            //   block's K rows [KB][HD] at the start of a key block
+  static constexpr int LDS = IMG + NIMG * IMG_BYTES;
+  static_assert(KB * HD * 2 <= IMG_BYTES, "K staging must fit one image");
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  // 8-byte chunk c of K row `row`: conflict-free transposed reads of rows {0..3, 8..11} / {4..7, 12..15}
+  // 8-byte chunk c of staged K row `row`: conflict-free transposed reads of rows {0..3, 8..11} / {4..7, 12..15}
   __device__ static __forceinline__ int kst_off(int row, int c) {
     if (HD == 32) return row * 64 + ((c ^ (((row >> 3) & 1) << 2)) << 3);
     const int sw = (row & 1) | (((row >> 2) & 1) << 1) | (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 3);
@@ -111,11 +95,11 @@ struct BwdCfg {
 };
 
 // bit permutation of the low 4 row bits: conflict-free ds_write_b64 by 16 consecutive rows AND conflict-free transposed reads
-// of rows {0..3, 8..11} / {4..7, 12..15} (attention backward)
+// of rows {0..3, 8..11} / {4..7, 12..15} (attention backward; SQ_LDS_BANK_CONFLICT reads 0.1 % of the LDS cycles)
 __device__ __forceinline__ int img_sw(int row) {
   return (row & 1) | (((row >> 2) & 1) << 1) | (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 3);
 }
-// byte offset of the 8-byte chunk c8 (4 queries) of key row `row` in the dS image (128-byte rows = 64 queries)
+// byte offset of the 8-byte chunk c8 (4 queries) of key row `row` in a dS image (128-byte rows = 64 queries)
 __device__ __forceinline__ int img_off(int row, int c8) { return row * 128 + ((c8 ^ img_sw(row)) << 3); }
 
 // s_waitcnt vmcnt(CNT) -- the CNT youngest vector-memory operations of this wave stay in flight
@@ -138,12 +122,6 @@ __device__ __forceinline__ void lds_dma4(unsigned m0v, unsigned voff, i32x4_t rs
   asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc) : "memory", "m0");
 #pragma clang diagnostic pop
 }
-// The lane id made opaque at this point: LDS address arithmetic derived from the result cannot be hoisted out of the
-// enclosing loop (hoisted, the dozens of per-lane offsets of the unrolled tile body live across the whole kernel and spill).
-__device__ __forceinline__ int opaque(int v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
 __device__ __forceinline__ i32x4_t make_rsrc(const void* base, unsigned bytes) {
   const unsigned long long a = (unsigned long long)base;
   i32x4_t r = {(int)(unsigned)a, (int)(unsigned)(a >> 32), (int)bytes, 0x00020000};
@@ -155,9 +133,8 @@ __device__ __forceinline__ i32x4_t make_rsrc(const void* base, unsigned bytes) {
 }
 
 // 8 bf16 A / B operand of a 32x32x16 or 16x16x32 MFMA from a PLAIN row-major [rows][rowb bytes] LDS array through two
-// transposed reads: element j = A[row0 + (j >> 2) * dr + (j & 3) ... ] -- see the call sites for the (row0, col0, dr) in use.
-//   lane 4q+p of each 16-lane group supplies row (row0 + q), columns col0 + 4p .. +3; lane i of the group receives column
-//   col0 + i of those 4 rows; the second read takes the rows `dr` further down.
+// transposed reads: lane 4q+p of each 16-lane group supplies row (row0 + q), columns col0 + 4p .. +3; lane i of the group
+// receives column col0 + i of those 4 rows; the second read takes the rows `dr` further down.
 __device__ __forceinline__ bf16x8 tr_pair(const char* base, int rowb, int row0, int col0, int dr, int lane) {
   const int q = (lane >> 2) & 3, p = lane & 3;
   const char* a = base + (row0 + q) * rowb + (col0 + 4 * p) * 2;
@@ -202,6 +179,7 @@ __global__ __launch_bounds__(256) void attn_rowconst_pad_kernel(const bf16_t* __
   }
 }
 
+
 // =====================================================================================================
 // main kernel: the full key blocks
 // =====================================================================================================
@@ -220,8 +198,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   // (batch, head) pair.  Consecutive block ids go to the 8 XCDs round robin; xcd_remap hands every XCD a CONTIGUOUS range of
-  // pairs instead, i.e. all 16 heads of a sample: their Q / dO rows are adjacent 64- or 128-byte pieces of the same lines,
-  // fetched once per XCD L2 instead of once per head.
+  // pairs instead, i.e. all 16 heads of a sample: their Q / dO rows are adjacent 64- or 128-byte pieces of the same lines.
+  // (Measured: no effect on the kernel time -- it is not memory bound -- but half the L2 misses.)
   const int bh = xcd_remap((int)blockIdx.x, (int)gridDim.x);
   const int b = bh / H, head = bh % H;
   const size_t rs = (size_t)3 * H * HD, os = (size_t)H * HD;
@@ -252,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
     disq[i] = isq;
   }
   const i32x4_t rsC = make_rsrc(rowc + (size_t)(wid & 1) * gridDim.x * NPAD + (size_t)bh * NPAD, (unsigned)((size_t)NPAD * 4));
-  auto issue = [&](int tt) {
+  auto issue = [&](int tt) {                     // Q / dO / constants of tile tt -> ring slot tt % NB   (PD + 1 operations)
     const int slot = tt % NB;
 #pragma unroll
     for (int i = 0; i < PD; ++i) {
@@ -274,49 +252,21 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
   const int khalf = C::PAIR ? (wid & 1) : 0;
   const int own = C::PAIR ? khalf : 0;            // PAIR: the tile (of its two) this wave keeps and read-modify-writes
   const int c16 = lane & 15, kg = lane >> 4;
-  unsigned wsoff[NT];                             // byte offset within tile 0's rows
+  unsigned wsoff[2];                              // byte offset within tile 0's rows of output tile qt = 2 qpair + i
 #pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    const int qt = 2 * qpair + (C::PAIR ? own : i);
-    wsoff[i] = (unsigned)(((16 * qt + c16) * HD + 16 * dt + 4 * kg) * 4);
-  }
+  for (int i = 0; i < 2; ++i) wsoff[i] = (unsigned)(((16 * (2 * qpair + i) + c16) * HD + 16 * dt + 4 * kg) * 4);
+  const unsigned wsown = own ? wsoff[1] : wsoff[0];
   const unsigned ws_tile = (unsigned)(64 * HD * 4);
-
-  // ---- LDS addressing: a few per-lane BASES + compile-time XOR masks + immediates.  The swizzles are XORs on chunk-index
-  // bits that the fragment index (k-step s, head-dim block d, sub-tile u) also occupies, so "address of fragment (u, s, d)" is
-  // base ^ mask(s, d) + constant(u, slot): one v_xor per read instead of the full index arithmetic (which, recomputed per
-  // use, made 2/3 of this kernel's VALU instructions integer work; hoisted by the compiler instead, it lived in ~60 VGPRs
-  // across the whole kernel and spilled).
-  //   row fragment (Tile::row_frag): row r, chunk (2s + h) ^ sw(r)            = rowb ^ (s << 5)          + 32u rows
-  //   transposed fragment (Tile::tr_frag): rows 16s + 4h + q (+8), chunk ((db>>3) + 2gi + (p>>1)) ^ sw(row)
-  //                                                                            = trb ^ (d << 6) [^ 32] + 16s rows (+8 rows)
-  //   dS image write: row krow, 8-byte chunk (8u + 4s + 2j + h) ^ img_sw(r)   = imgb ^ ((8u + 4s + 2j) << 3)
+  // dQ product operands (transposed reads): dS image rows 32 ks + 8 kg + q4 (+4), chunk (4 qt + p) ^ img_sw(row); the second
+  // output tile (qt + 1) is chunk bit 2, i.e. address ^ 32
   const int q4 = (lane >> 2) & 3, p4 = lane & 3;
-#if BWD_PIPE != 0
-  const int gi = (lane >> 4) & 1;
-#endif
-#if BWD_PIPE != 0
-  const int rowb = r * T::ROWB + ((h ^ T::sw(r)) << 4);
-  const int trb = (4 * h + q4) * T::ROWB + (((2 * gi + (p4 >> 1)) ^ T::sw(4 * h + q4)) << 4) + (p4 & 1) * 8;
-  const int imgb = C::IMG + (wid * C::KW + r) * 128 + ((h ^ img_sw(r)) << 3);
-  const int cstb = 16 * h;
-#endif
-  // phase 2 (dQ product): dS image rows 32 ks + 8 kg + q4 (+4), chunk (4 qt + p) ^ img_sw(row); staged K rows likewise
   const int p2row = khalf * C::KH + 8 * kg + q4;
   const int p2a0 = C::IMG + p2row * 128 + (((8 * qpair + p4) ^ img_sw((8 * kg + q4) & 15)) << 3);
   const int p2a1 = C::IMG + (p2row + 4) * 128 + (((8 * qpair + p4) ^ img_sw((8 * kg + q4 + 4) & 15)) << 3);
-  const int p2k0 = C::KST + C::kst_off(p2row, 4 * dt + p4);
-  const int p2k1 = C::KST + C::kst_off(p2row + 4, 4 * dt + p4);
 
-#if BWD_PRIO
-  // waves 4-7 are the SIMD partners of waves 0-3 and, being younger, lose every arbitration for the vector and matrix issue
-  // ports: in-kernel stamps had them finish a tile's units 30 % after waves 0-3, which then idle at the barrier.  One static
-  // priority raise (MI355X_MICROARCH.md, "Two waves per SIMD", item 4); no per-segment flips.
-  if (wid >= 4) __builtin_amdgcn_s_setprio(BWD_PRIO);
-#endif
   for (int kb = 0; kb < nkb; ++kb) {
     const int key0 = kb * C::KB;
-    // ---- stage this block's K rows in LDS for the transposed reads of the dQ product (A operand K^T)
+    // ---- stage this block's K rows in image 0 for the transposed reads of the loop-invariant K^T fragments
     {
       constexpr int CH = HD / 8;                 // 16-byte chunks per row
       constexpr int TOTAL = C::KB * CH;
@@ -325,8 +275,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
         const int c = tid + 512 * i;
         const int row = c / CH, cc = c % CH;
         const u32x4 v = *reinterpret_cast<const u32x4*>(kb_ + (size_t)(key0 + row) * rs + 8 * cc);
-        *reinterpret_cast<u32x2*>(smem + C::KST + C::kst_off(row, 2 * cc)) = u32x2{v[0], v[1]};
-        *reinterpret_cast<u32x2*>(smem + C::KST + C::kst_off(row, 2 * cc + 1)) = u32x2{v[2], v[3]};
+        *reinterpret_cast<u32x2*>(smem + C::IMG + C::kst_off(row, 2 * cc)) = u32x2{v[0], v[1]};
+        *reinterpret_cast<u32x2*>(smem + C::IMG + C::kst_off(row, 2 * cc + 1)) = u32x2{v[2], v[3]};
       }
     }
     // ---- this wave's keys: B operands of S (pre-scaled) and dP
@@ -350,12 +300,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
 #pragma unroll
         for (int e = 0; e < 16; ++e) { dk[g][d][e] = 0.f; dv[g][d][e] = 0.f; }
     __syncthreads();                              // K staging visible
-#if BWD_KT_REGS
-    bf16x8 kTr[C::QSTEPS];                        // loop-invariant A operands of the dQ product, read once per key block
+    // A operand of dQ^T = K^T dS^T: K^T[row d = 16 dt + c16][k = key 32 ks + 8 kg + j], loop invariant, read once per block
+    bf16x8 kT[C::QSTEPS];
 #pragma unroll
     for (int ks = 0; ks < C::QSTEPS; ++ks)
-      kTr[ks] = cat4(lds_tr_read(smem + p2k0 + ks * 32 * HD * 2), lds_tr_read(smem + p2k1 + ks * 32 * HD * 2));
-#endif
+      kT[ks] = cat4(lds_tr_read(smem + C::IMG + C::kst_off(p2row, 4 * dt + p4) + ks * 32 * HD * 2),
+                    lds_tr_read(smem + C::IMG + C::kst_off(p2row + 4, 4 * dt + p4) + ks * 32 * HD * 2));
+    wait_lgkm0();
+    __syncthreads();                              // every wave has its K^T fragments: image 0 is free
 
     // ---- ring prologue
     issue(0);
@@ -364,60 +316,51 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
     wait_lgkm0();
     __builtin_amdgcn_s_barrier();
 
-    f32x4_t acc0, acc1;                           // dQ^T partial tiles (qt = 2 qpair, 2 qpair + 1)
-    acc0 = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    acc1 = acc0;
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;   // dQ^T partial tiles (qt = 2 qpair, 2 qpair + 1) of the tile last multiplied
     const char* myold = smem + C::OLD + wid * NT * 1024 + lane * 16;
 
-    // finish(tp): tile tp's dQ^T -> workspace.  Its partial sums are in acc0/acc1 (and, PAIR, in the partner's exchange
-    // slot); the workspace values were requested at the start of tile tp by LDS-DMA into this wave's OLD slot (a register
-    // load would make the compiler drain the whole DMA ring at its first use).
-    auto finish = [&](int tp) {
-      wait_vm<PD + 1>();                          // everything older than tile tp+2's PD+1 DMAs has landed: OLD(tp) included
-      if (C::PAIR) {
-        const f32x4_t other = *reinterpret_cast<const f32x4_t*>(smem + C::XCH + (wid ^ 1) * 1024 + lane * 16);
-        f32x4_t v = (own ? acc1 : acc0) + other;
-        if (kb > 0) v += *reinterpret_cast<const f32x4_t*>(myold);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsWs, wsoff[0] + (unsigned)tp * ws_tile, 0, 0);
-      } else {
-        f32x4_t v0 = acc0, v1 = acc1;
-        if (kb > 0) {
-          v0 += *reinterpret_cast<const f32x4_t*>(myold);
-          v1 += *reinterpret_cast<const f32x4_t*>(myold + (NT - 1) * 1024);
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), rsWs, wsoff[0] + (unsigned)tp * ws_tile, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), rsWs, wsoff[NT - 1] + (unsigned)tp * ws_tile, 0, 0);
-      }
-      wait_lgkm0();                               // the OLD / exchange reads have returned before anything rewrites them
-    };
-
-#ifdef BWD_STAMP
-    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long tlast = stamp();
-#endif
-    for (int t = 0; t < ntiles; ++t) {
-      // ---- phase 1: previous tile's dQ out, this tile's requests, S / dP / P / dS, dS -> image, dV / dK
-      if (t > 0) finish(t - 1);
+    // request the workspace values of tile tp's output tile(s) into this wave's OLD slot (NT operations; LDS-DMA, because a
+    // register load would make the compiler drain the whole DMA ring at its first use)
+    auto oldreq = [&](int tp) {
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
         const unsigned m0o = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + C::OLD + (wid * NT + i) * 1024));
-        lds_dma16(m0o, wsoff[i] + (unsigned)t * ws_tile, rsW);
+        lds_dma16(m0o, (C::PAIR ? wsown : wsoff[i]) + (unsigned)tp * ws_tile, rsW);
       }
-      issue(t + 2);
-      STAMP(0);
-      // this tile's bases (opaque: whatever is derived from them stays inside the tile loop, in a handful of registers)
+    };
+    // finish(tp): tile tp's dQ^T -> workspace (NT stores).  Its partial sums are in acc0 / acc1 and, PAIR, in the partner's
+    // exchange slot; YOUNGER operations of this wave allowed to stay in flight while OLD(tp) is waited for.
+    auto finish = [&](int tp, auto younger_) {
+      wait_vm<decltype(younger_)::value>();
+      const f32x4_t o0 = *reinterpret_cast<const f32x4_t*>(myold);
+      const f32x4_t o1 = *reinterpret_cast<const f32x4_t*>(myold + (NT - 1) * 1024);
+      if (C::PAIR) {
+        const f32x4_t other = *reinterpret_cast<const f32x4_t*>(smem + C::XCH + (wid ^ 1) * 1024 + lane * 16);
+        f32x4_t v = (own ? acc1 : acc0) + other;
+        if (kb > 0) v += o0;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsWs, wsown + (unsigned)tp * ws_tile, 0, 0);
+      } else {
+        f32x4_t v0 = acc0, v1 = acc1;
+        if (kb > 0) {
+          v0 += o0;
+          v1 += o1;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), rsWs, wsoff[0] + (unsigned)tp * ws_tile, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), rsWs, wsoff[1] + (unsigned)tp * ws_tile, 0, 0);
+      }
+      wait_lgkm0();                               // the OLD / exchange reads have returned before anything rewrites them
+    };
+    // units(t): S / dP / P / dS of tile t against this wave's keys, dS -> image t % NIMG, dV^T / dK^T accumulate.  Per 32-query
+    // sub-tile the row constants and the Q / dO fragments are read ONCE and shared by the wave's key groups.
+    auto units = [&](int t) {
       const int slot = t % NB;
-      const int slotq = C::QR + slot * T::BYTES;          // scalar
-#if BWD_PIPE == 0
-      // Plain form: per 32-query sub-tile the row constants and the Q / dO fragments are read ONCE and shared by the wave's
-      // key groups (least LDS traffic and fewest instructions; no explicit software pipeline -- the partner wave and the
-      // compiler's own scheduling provide the overlap).
+      const char* cQ = smem + C::QR + slot * T::BYTES;
+      const char* cO = smem + C::OR_ + slot * T::BYTES;
+      const float* cC = reinterpret_cast<const float*>(smem + C::CR + slot * 512);
+      char* img = smem + C::IMG + (t % C::NIMG) * C::IMG_BYTES;
 #pragma unroll 1
       for (int u = 0; u < 2; ++u) {
         f32x16 lse_t, dlt_t;                      // row constants: register 4G+e <-> query row 32u + 8G + 4h + e
-        const float* cC = reinterpret_cast<const float*>(smem + C::CR + slot * 512);
-        const char* cQ = smem + slotq;
-        const char* cO = cQ + (C::OR_ - C::QR);
 #pragma unroll
         for (int G = 0; G < 4; ++G) {
           const f32x4 a = *reinterpret_cast<const f32x4*>(cC + 32 * u + 8 * G + 4 * h);
@@ -425,7 +368,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
 #pragma unroll
           for (int e = 0; e < 4; ++e) { lse_t[4 * G + e] = a[e]; dlt_t[4 * G + e] = d[e]; }
         }
-        bf16x8 qrow[KS], orow[KS], qT2[2][DB], oT2[2][DB];
+        bf16x8 qrow[KS], orow[KS], qT[2][DB], oT[2][DB];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
           qrow[s] = T::row_frag(cQ, 32 * u, s, lane);
@@ -435,12 +378,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
         for (int s = 0; s < 2; ++s)
 #pragma unroll
           for (int d = 0; d < DB; ++d) {
-            qT2[s][d] = T::tr_frag(cQ, 32 * u, s, 32 * d, lane);
-            oT2[s][d] = T::tr_frag(cO, 32 * u, s, 32 * d, lane);
+            qT[s][d] = T::tr_frag(cQ, 32 * u, s, 32 * d, lane);
+            oT[s][d] = T::tr_frag(cO, 32 * u, s, 32 * d, lane);
           }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-          f32x16 sa = mfma32(qrow[0], kS[g][0], lse_t);
+          f32x16 sa = mfma32(qrow[0], kS[g][0], lse_t);                  // row constants as the initial accumulators
 #pragma unroll
           for (int s = 1; s < KS; ++s) sa = mfma32(qrow[s], kS[g][s], sa);
           f32x16 dp = mfma32(orow[0], vS[g][0], dlt_t);
@@ -458,207 +401,55 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
             const bf16x8 pf = acc_to_frag(sa, s);
             const bf16x8 dsf = acc_to_frag(dp, s);
             const u32x4 w = __builtin_bit_cast(u32x4, dsf);
-            *reinterpret_cast<u32x2*>(smem + C::IMG + img_off(krow, 8 * u + 4 * s + h)) = u32x2{w[0], w[1]};
-            *reinterpret_cast<u32x2*>(smem + C::IMG + img_off(krow, 8 * u + 4 * s + 2 + h)) = u32x2{w[2], w[3]};
+            // registers 8s..8s+3 <-> queries 32u + 16s + 4h + 0..3 ; 8s+4..8s+7 <-> 32u + 16s + 8 + 4h + 0..3
+            *reinterpret_cast<u32x2*>(img + img_off(krow, 8 * u + 4 * s + h)) = u32x2{w[0], w[1]};
+            *reinterpret_cast<u32x2*>(img + img_off(krow, 8 * u + 4 * s + 2 + h)) = u32x2{w[2], w[3]};
 #pragma unroll
             for (int d = 0; d < DB; ++d) {
-              dv[g][d] = mfma32(oT2[s][d], pf, dv[g][d]);
-              dk[g][d] = mfma32(qT2[s][d], dsf, dk[g][d]);
+              dv[g][d] = mfma32(oT[s][d], pf, dv[g][d]);
+              dk[g][d] = mfma32(qT[s][d], dsf, dk[g][d]);
             }
           }
         }
       }
-#else
-      // Units (32 queries x 32 keys of this wave) are software-pipelined by hand, the order pinned with sched_barrier:
-      //   R  LDS reads of unit n+1's operands (row constants straight into its accumulators, Q / dO row fragments) and of
-      //      unit n's transposed Q / dO fragments            -- their latency passes under V1
-      //   V1 exp2 and the dS product of unit n
-      //   M1 S and dP MFMAs of unit n+1                       -- execute under V2
-      //   V2 bf16 packing of P and dS of unit n, dS -> image
-      //   M2 dV^T and dK^T MFMAs of unit n                    -- execute under the next R / V1
-      // Exposed LDS latency was what serialised the unpipelined form (in-kernel stamps: a wave spent ~1200 cycles per unit,
-      // four times its issue work).
-      constexpr int NU = 2 * NG;
-      auto loadA = [&](auto n_, f32x16& sa, f32x16& dp, bf16x8 (&qf)[KS], bf16x8 (&of)[KS]) {
-        constexpr int n = decltype(n_)::value, u = n / NG;
-        const char* cCb = smem + C::CR + slot * 512 + opaque(cstb);
-        const int rowt = opaque(rowb) + slotq;
+    };
+    // dqmul(tq): this wave's dQ^T tiles of tile tq over its KH keys of the image -> acc0 / acc1; PAIR: the tile this wave
+    // does not keep goes to its exchange slot, where the partner picks it up
+    auto dqmul = [&](int tq) {
+      const int ib = (tq % C::NIMG) * C::IMG_BYTES;
+      const char* a00 = smem + p2a0 + ib;
+      const char* a01 = smem + p2a1 + ib;
+      const char* a10 = smem + (p2a0 ^ 32) + ib;
+      const char* a11 = smem + (p2a1 ^ 32) + ib;
+      acc0 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      acc1 = acc0;
 #pragma unroll
-        for (int G = 0; G < 4; ++G) {             // row constants as the initial accumulators: register 4G+e <-> query 32u + 8G + 4h + e
-          const f32x4 a = *reinterpret_cast<const f32x4*>(cCb + (32 * u + 8 * G) * 4);
-          const f32x4 d = *reinterpret_cast<const f32x4*>(cCb + (64 + 32 * u + 8 * G) * 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { sa[4 * G + e] = a[e]; dp[4 * G + e] = d[e]; }
-        }
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const char* a = smem + ((rowt ^ (s << 5)) + 32 * u * T::ROWB);
-          qf[s] = *reinterpret_cast<const bf16x8*>(a);
-          of[s] = *reinterpret_cast<const bf16x8*>(a + (C::OR_ - C::QR));
-        }
-      };
-      auto loadC = [&](auto n_, bf16x8 (&oT)[2][DB], bf16x8 (&qT)[2][DB]) {
-        constexpr int n = decltype(n_)::value, u = n / NG;
-        const int trt = opaque(trb) + slotq;
-#pragma unroll
-        for (int d = 0; d < DB; ++d) {
-          const char* lo = smem + ((trt ^ (d << 6)) + 32 * u * T::ROWB);            // rows 16s + 4h + q
-          const char* hi = smem + ((trt ^ (d << 6) ^ 32) + (32 * u + 8) * T::ROWB);  // rows 16s + 8 + 4h + q: sw differs in bit 1
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            qT[s][d] = cat4(lds_tr_read(lo + 16 * s * T::ROWB), lds_tr_read(hi + 16 * s * T::ROWB));
-            oT[s][d] = cat4(lds_tr_read(lo + 16 * s * T::ROWB + (C::OR_ - C::QR)), lds_tr_read(hi + 16 * s * T::ROWB + (C::OR_ - C::QR)));
-          }
-        }
-      };
-      auto mmaA = [&](auto n_, f32x16& sa, f32x16& dp, const bf16x8 (&qf)[KS], const bf16x8 (&of)[KS]) {
-        constexpr int n = decltype(n_)::value, g = n % NG;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) sa = mfma32(qf[s], kS[g][s], sa);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) dp = mfma32(of[s], vS[g][s], dp);
-      };
-      auto expmul = [&](f32x16& sa, f32x16& dp) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float p = fast_exp2(sa[e]);
-          sa[e] = p;
-          dp[e] = p * dp[e];                      // dS / scale
-        }
-      };
-      auto pack = [&](auto n_, const f32x16& sa, const f32x16& dp, bf16x8 (&pf)[2], bf16x8 (&dsf)[2]) {
-        constexpr int n = decltype(n_)::value, u = n / NG, g = n % NG;
-        const int imgt = opaque(imgb);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          pf[s] = acc_to_frag(sa, s);
-          dsf[s] = acc_to_frag(dp, s);
-          const u32x4 w = __builtin_bit_cast(u32x4, dsf[s]);
-          // registers 8s..8s+3 <-> queries 32u + 16s + 4h + 0..3 ; 8s+4..8s+7 <-> 32u + 16s + 8 + 4h + 0..3
-          *reinterpret_cast<u32x2*>(smem + ((imgt ^ ((8 * u + 4 * s) << 3)) + 32 * g * 128)) = u32x2{w[0], w[1]};
-          *reinterpret_cast<u32x2*>(smem + ((imgt ^ ((8 * u + 4 * s + 2) << 3)) + 32 * g * 128)) = u32x2{w[2], w[3]};
-        }
-      };
-      auto mmaC = [&](auto n_, const bf16x8 (&pf)[2], const bf16x8 (&dsf)[2], const bf16x8 (&oT)[2][DB], const bf16x8 (&qT)[2][DB]) {
-        constexpr int n = decltype(n_)::value, g = n % NG;
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int d = 0; d < DB; ++d) {
-            dv[g][d] = mfma32(oT[s][d], pf[s], dv[g][d]);
-            dk[g][d] = mfma32(qT[s][d], dsf[s], dk[g][d]);
-          }
-      };
-      {
-        f32x16 sX, pX, sY, pY;
-        bf16x8 qf[KS], of[KS], oT[2][DB], qT[2][DB], pf[2], dsf[2];
-#define SB() __builtin_amdgcn_sched_barrier(0)
-#define IC(n) std::integral_constant<int, n>{}
-#if BWD_STAGGER > 0
-        if (wid >= 4) __builtin_amdgcn_s_sleep(BWD_STAGGER);
-#endif
-#if BWD_PIPE != 0
-        // Three units in flight.  Every region pairs MFMAs with INDEPENDENT vector work of another unit, interleaved by
-        // sched_group_barrier, so that one wave overlaps the two pipes by itself (its SIMD partner runs the same code at
-        // about the same place and competes for the same pipe at the same time):
-        //   Y_k: S / dP MFMAs of unit k+1  ||  bf16 packing of P, dS of unit k + dS -> image      (+ transposed reads for X_k)
-        //   X_k: dV^T / dK^T MFMAs of unit k  ||  exp2 and dS product of unit k+1                  (+ operand reads of unit k+2)
-#define MFMA_VALU(nm, nv, rep)                                                         \
-        _Pragma("unroll") for (int i_ = 0; i_ < rep; ++i_) {                          \
-          __builtin_amdgcn_sched_group_barrier(0x008, nm, 0);                          \
-          __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);                          \
-        }
-#define MFMA_TRANS_VALU(nm, nt, nv, rep)                                               \
-        _Pragma("unroll") for (int i_ = 0; i_ < rep; ++i_) {                          \
-          __builtin_amdgcn_sched_group_barrier(0x008, nm, 0);                          \
-          __builtin_amdgcn_sched_group_barrier(0x400, nt, 0);                          \
-          __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);                          \
-        }
-        constexpr int NM = 2 * KS;                       // MFMAs per region
-        loadA(IC(0), sX, pX, qf, of); SB();
-        mmaA(IC(0), sX, pX, qf, of); SB();
-        loadA(IC(1), sY, pY, qf, of); SB();
-        expmul(sX, pX); SB();
-#define STEP(k, SK, PK, SN, PN, HASN1, HASN2)                                          \
-        loadC(IC(k), oT, qT); SB();                                                    \
-        if constexpr (HASN1) mmaA(IC(k + 1), SN, PN, qf, of);                          \
-        pack(IC(k), SK, PK, pf, dsf);                                                  \
-        if constexpr (HASN1) { MFMA_VALU(1, 16 / NM + 1, NM) }                         \
-        SB();                                                                          \
-        if constexpr (HASN2) loadA(IC(k + 2), SK, PK, qf, of);                         \
-        SB();                                                                          \
-        mmaC(IC(k), pf, dsf, oT, qT);                                                  \
-        if constexpr (HASN1) expmul(SN, PN);                                           \
-        if constexpr (HASN1) { MFMA_TRANS_VALU(1, 16 / NM, 8 / NM, NM) }               \
-        SB();
-        if constexpr (NU == 2) {
-          STEP(0, sX, pX, sY, pY, true, false)
-          STEP(1, sY, pY, sX, pX, false, false)
-        } else {
-          STEP(0, sX, pX, sY, pY, true, true)
-          STEP(1, sY, pY, sX, pX, true, true)
-          STEP(2, sX, pX, sY, pY, true, false)
-          STEP(3, sY, pY, sX, pX, false, false)
-        }
-#undef STEP
-#undef MFMA_VALU
-#undef MFMA_TRANS_VALU
-#endif
-#undef SB
-#undef IC
+      for (int ks = 0; ks < C::QSTEPS; ++ks) {
+        const bf16x8 b0 = cat4(lds_tr_read(a00 + ks * 32 * 128), lds_tr_read(a01 + ks * 32 * 128));
+        const bf16x8 b1 = cat4(lds_tr_read(a10 + ks * 32 * 128), lds_tr_read(a11 + ks * 32 * 128));
+        acc0 = mfma16(kT[ks], b0, acc0);
+        acc1 = mfma16(kT[ks], b1, acc1);
       }
+      if (C::PAIR) *reinterpret_cast<f32x4_t*>(smem + C::XCH + wid * 1024 + lane * 16) = own ? acc0 : acc1;
+    };
+    using IC0 = std::integral_constant<int, 0>;
+    using ICD = std::integral_constant<int, PD + 1>;
+
+#ifdef BWD_STAMP
+    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = stamp();
 #endif
+    for (int t = 0; t < ntiles; ++t) {
+      if (t > 0) finish(t - 1, ICD{});
+      oldreq(t);
+      issue(t + 2);
+      STAMP(0);
+      units(t);
       STAMP(1);
       wait_lgkm0();
       __builtin_amdgcn_s_barrier();               // A: the image of tile t is complete
       STAMP(2);
-      // ---- phase 2: dQ^T tiles of this wave over its KH keys
-      acc0 = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      acc1 = acc0;
-      {
-        // B operand dS^T[k = key][col q] of the two output tiles (qt = 2 qpair, 2 qpair + 1: chunk bit 2) and the A operand
-        // K^T[row d = 16 dt + c16][k = key 32 ks + 8 kg + j] from the staged K rows, all by transposed reads
-        const char* a00 = smem + opaque(p2a0);
-        const char* a01 = smem + opaque(p2a1);
-        const char* a10 = smem + (opaque(p2a0) ^ 32);
-        const char* a11 = smem + (opaque(p2a1) ^ 32);
-#if !BWD_KT_REGS
-        const char* k0 = smem + opaque(p2k0);
-        const char* k1 = smem + opaque(p2k1);
-#endif
-#if BWD_P2_PRELOAD
-        // every operand first (the unit pipeline's registers are free here), then the MFMAs back to back: with the reads
-        // issued a k-step or two ahead, as the compiler orders them, this phase took 900-1400 cycles for 256 cycles of MFMAs
-        bf16x8 ka[C::QSTEPS], b0[C::QSTEPS], b1[C::QSTEPS];
-#pragma unroll
-        for (int ks = 0; ks < C::QSTEPS; ++ks) {
-          ka[ks] = cat4(lds_tr_read(k0 + ks * 32 * HD * 2), lds_tr_read(k1 + ks * 32 * HD * 2));
-          b0[ks] = cat4(lds_tr_read(a00 + ks * 32 * 128), lds_tr_read(a01 + ks * 32 * 128));
-          b1[ks] = cat4(lds_tr_read(a10 + ks * 32 * 128), lds_tr_read(a11 + ks * 32 * 128));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < C::QSTEPS; ++ks) {
-          acc0 = mfma16(ka[ks], b0[ks], acc0);
-          acc1 = mfma16(ka[ks], b1[ks], acc1);
-        }
-#else
-#pragma unroll
-        for (int ks = 0; ks < C::QSTEPS; ++ks) {
-#if BWD_KT_REGS
-          const bf16x8 ka = kTr[ks];
-#else
-          const bf16x8 ka = cat4(lds_tr_read(k0 + ks * 32 * HD * 2), lds_tr_read(k1 + ks * 32 * HD * 2));
-#endif
-          const bf16x8 b0 = cat4(lds_tr_read(a00 + ks * 32 * 128), lds_tr_read(a01 + ks * 32 * 128));
-          const bf16x8 b1 = cat4(lds_tr_read(a10 + ks * 32 * 128), lds_tr_read(a11 + ks * 32 * 128));
-          acc0 = mfma16(ka, b0, acc0);
-          acc1 = mfma16(ka, b1, acc1);
-        }
-#endif
-      }
-      if (C::PAIR)                                 // hand the tile this wave does not keep to its partner
-        *reinterpret_cast<f32x4_t*>(smem + C::XCH + wid * 1024 + lane * 16) = own ? acc0 : acc1;
+      dqmul(t);
       STAMP(3);
       if (t == 0) wait_vm<NT + PD + 1>();         // tile t+1 landed (younger: this tile's NT loads, tile t+2's DMAs ...
       else wait_vm<2 * NT + PD + 1>();            //  ... and, from the second tile on, the NT stores of finish(t-1))
@@ -671,7 +462,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
     if (kb == 0 && lane == 0 && blockIdx.x < 512)
       for (int i = 0; i < 6; ++i) g_bwd_stamp[(blockIdx.x * 8 + wid) * 8 + i] = seg[i];
 #endif
-    finish(ntiles - 1);
+    finish(ntiles - 1, ICD{});
     // ---- dK, dV of this wave's keys
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -688,7 +479,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
         }
     }
     // the next block's workspace read-modify-write of a row is done by the same lane as this block's: program order;
-    // drain everything (stale DMA of tiles past the end included) before the K staging reuses the image region
+    // drain everything (stale DMA of tiles past the end included) before the K staging reuses image 0
     wait_vm<0>();
     __syncthreads();
   }
