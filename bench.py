@@ -14,7 +14,10 @@ from the device RNG inside the timed region.  Rank 0 prints ONE JSON line.
 
 The line also carries
   roofline     -- the dominant kernel of the timed region (by summed device time, measured with HIP events recorded on the
-                  launch stream around every MFMA kernel launch): algorithmic FLOP / measured time vs the dense bf16 MFMA peak
+                  launch stream around every 5th call of each MFMA entry point): algorithmic FLOP / measured time vs the dense
+                  bf16 MFMA peak.  `rocprof_kernels` names the kernel(s) one call launches (the fused attention backward is
+                  three: row constants, main kernel, tail) -- `avg_launch_us` is the sum of their rocprofv3 averages and
+                  `traffic` the sum of their PMC bytes; `executed_tflops` counts the recomputed matmuls as well
   cpu_baseline -- the CPU oracle (oracle/mae3d_ref.py, a port of the reference's non-flash model) timed on this host's
                   cores for ONE volume forward+backward (rank 0, N = 1 only)
 """
@@ -70,6 +73,10 @@ _PMC_KERNEL = {"gemm_wgrad_epi5": ["gemm256p_kernel<true, true, 5, true>", "gemm
                "attn_bwd_dq_hd32": ["attn_bwd_dq_kernel<32>"], "attn_bwd_dq_hd64": ["attn_bwd_dq_kernel<64>"],
                "attn_bwd_dkv_hd32": ["attn_bwd_dkv_kernel<32>"], "attn_bwd_dkv_hd64": ["attn_bwd_dkv_kernel<64>"],
                "attn_bwd_fused_hd32": ["attn_bwd_fused_kernel<32>"], "attn_bwd_fused_hd64": ["attn_bwd_fused_kernel<64>"]}
+# A timed kind that is one C-ABI entry point but several launches: the HIP events bracket the whole entry, so `avg_launch_us`
+# is the SUM of these kernels' average durations in a rocprofv3 summary, and `traffic` the sum of their bytes.
+_LAUNCH_GROUP = {"attn_bwd_fused_hd32": ["attn_rowconst_pad_kernel<32>", "attn_bwd_fused_kernel<32>", "attn_bwd_tail_kernel<32>"],
+                 "attn_bwd_fused_hd64": ["attn_rowconst_pad_kernel<64>", "attn_bwd_fused_kernel<64>", "attn_bwd_tail_kernel<64>"]}
 
 
 def pmc_traffic(kind, micro_batch):
@@ -84,6 +91,9 @@ def pmc_traffic(kind, micro_batch):
             meta = t.get("_meta", {})
             if int(meta.get("micro_batch", 32)) != micro_batch:
                 continue
+            group = _LAUNCH_GROUP.get(kind)
+            if group and all(name in t for name in group):
+                return (sum(t[name]["hbm_bytes_per_launch_corrected"] for name in group), os.path.basename(path), meta.get("head"))
             for name in _PMC_KERNEL.get(kind, []):
                 if name in t:
                     return t[name]["hbm_bytes_per_launch_corrected"], os.path.basename(path), meta.get("head")
@@ -107,6 +117,12 @@ def main():
     ap.add_argument("--force-reducer", action="store_true", help="single rank: still create the RCCL group and run the reducer")
     ap.add_argument("--torch-nccl", action="store_true", help="exchange through torch.distributed's NCCL group instead of octmae_comm_*")
     args = ap.parse_args()
+
+    # ONE line on stdout: RCCL prints a version banner to stdout when a communicator is created (NCCL_DEBUG=VERSION/WARN), and
+    # any library may print.  File descriptor 1 is pointed at stderr for the whole run; the JSON line goes to the saved one.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -246,6 +262,7 @@ def main():
                                "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": tsrc, "traffic_head": thead,
                                "executed_tflops": exe, "executed_frac": exe / PEAK_BF16_TFLOPS,
                                "avg_launch_us": d["avg_us"], "launches": d["launches"],
+                               "rocprof_kernels": _LAUNCH_GROUP.get(dom, _PMC_KERNEL.get(dom, [dom])[:1]),
                                "share_of_timed_mfma_kernels": d["total_ms"] / tot,
                                "accounting": "algorithmic: attention fwd 4BHN^2hd, bwd 8BHN^2hd (x3 total), GEMM 2*NA*NB*K"}
             out["kernels"] = {k: {"ms": round(v["total_ms"], 3), "avg_us": round(v["avg_us"], 2), "launches": v["launches"],
@@ -259,7 +276,12 @@ def main():
                 out["attention_qk_pv"] = {"tflops": fl / (ms * 1e-3) / 1e12, "frac_of_bf16_peak": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                                           "executed_tflops": xfl / (ms * 1e-3) / 1e12, "ms": ms}
         if use_dist:
-            out["comm"] = {"backend": comm_kind, "reducer": dict(reducer.stats) if reducer is not None else None}
+            red = None
+            if reducer is not None:
+                red = dict(reducer.stats)
+                red["chunk_mb"] = [round(4 * (e - s_) / 1e6, 1) for s_, e in reducer.bounds]
+                red["cold_chunk"] = [bool(c) for c in reducer.cold_chunk]
+            out["comm"] = {"backend": comm_kind, "reducer": red}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()
@@ -281,7 +303,8 @@ def main():
         except Exception:
             pass
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -12,10 +12,14 @@ gradient arena and RCCL over xGMI.
     latency better than DDP's 25 MB buckets;
   * a chunk is all-reduced as soon as every parameter in it has reported its gradient (ops.notify_grad_ready, fired by
     the backward Functions; autograd hooks for the few PyTorch-side parameters), i.e. overlapped with the rest of backward;
-  * chunks follow READINESS, not just offsets: parameters that reported no gradient in the previous exchanged backward
-    (``high_res_patch_embed`` on 256x256 input) are cut out into chunks of their own, so they no longer hold
-    back the ~166 MB slice they sit in; those "cold" chunks (3 MB for ViT-L) are exchanged in finish() -- zeros unless this
-    backward did use them, which is why they cannot simply be launched up front;
+  * chunks follow READINESS, not just offsets: parameters that reported no gradient on ANY rank in the first exchanged
+    backward (``high_res_patch_embed`` in the 3-D-only step) are cut out into chunks of their own, so they no
+    longer hold back the ~166 MB slice they sit in.  The set is agreed across ranks once (one MAX all-reduce of a
+    per-parameter mask at the end of that first step -- the ranks' collectives must have the same sizes) and then FROZEN:
+    from the second exchanged step on the "cold" chunks (zeros in the arena) are launched in begin_backward(), under the
+    whole backward.  A cold parameter that receives a gradient later is a change of the model's control flow after the
+    layout was learned: the early exchange may race with the kernel that wrote it, so the reducer raises instead of
+    exchanging something wrong (``relearn()`` starts the learning step over);
   * with gradient accumulation the exchange happens only on the LAST micro-step (the reference all-reduces on every
     micro-step, engine_pretrain.py:163-170 -- identical result, 1/accum_iter the traffic).
 Works on CPU with the gloo backend for tests (then the "stream" is the caller's thread).
@@ -49,7 +53,8 @@ class FlatGradReducer:
         self._pending: List = []
         self._hooks = []
         self._comm_stream = None
-        self._cold = frozenset()    # ids of parameters that reported nothing in the last exchanged backward
+        self._cold = frozenset()    # ids of parameters that reported nothing, on any rank, in the learning step
+        self._frozen = False        # True once the cold set has been agreed across ranks (after the first exchanged backward)
         self._seen = set()
         # A parameter used by SEVERAL forwards of one backward (the joint 3-D + 2-D/512 loop) reports once per use, and its
         # chunk may only go out after the last report.  multi_use = True: the first exchanged backward runs without overlap
@@ -57,7 +62,8 @@ class FlatGradReducer:
         self.multi_use = False
         self._expected = None       # id(param) -> reports per backward, learned
         self._reports = {}
-        self.stats = {"launched_in_backward": 0, "launched_in_finish": 0, "bytes_in_finish": 0, "bytes_total": 0}
+        self.stats = {"launched_in_backward": 0, "launched_in_finish": 0, "bytes_in_finish": 0, "bytes_total": 0,
+                      "last_launch_bytes": 0}
 
     # ------------------------------------------------------------------ layout
     def _layout(self, rebuild: bool = False):
@@ -123,6 +129,11 @@ class FlatGradReducer:
         self._reports = {}
         self._overlap_now = self._sync and self.overlap and not (self.multi_use and self._expected is None)
         ops.set_grad_ready_callback(self._on_ready if self._overlap_now else self._on_ready_note)
+        if self._overlap_now and self._frozen:
+            # chunks made only of parameters that never report (zeros in the arena) are exchanged NOW, under the whole backward
+            for c in range(len(self.bounds)):
+                if self.cold_chunk[c]:
+                    self._launch(c)
 
     def _autograd_hook(self, p):
         if getattr(self, "_overlap_now", False):
@@ -153,6 +164,10 @@ class FlatGradReducer:
             self._seen.add(k)
             for c in self.chunk_of[k]:
                 self._remaining[c] -= 1
+                if self._launched[c]:
+                    raise RuntimeError("FlatGradReducer: a parameter that reported no gradient on any rank in the learning step "
+                                       "received one now, after its chunk was exchanged at begin_backward(); the model's "
+                                       "control flow changed -- call reducer.relearn() before such a step")
                 if self._remaining[c] == 0:
                     self._launch(c)
 
@@ -164,6 +179,7 @@ class FlatGradReducer:
         buf = self._arena.grad[s:e]
         nbytes = 4 * (e - s)
         self.stats["bytes_total"] += nbytes
+        self.stats["last_launch_bytes"] = nbytes        # after finish(): the chunk that went out last (its exchange is the exposed tail)
         if self._in_backward:
             self.stats["launched_in_backward"] += 1
         else:
@@ -201,12 +217,36 @@ class FlatGradReducer:
         self._pending = []
         if self.multi_use and self._expected is None:
             self._expected = dict(self._reports)
-        # readiness statistics for the next step's chunk layout: whoever did not report is "cold"
-        if self.overlap:
-            cold = frozenset(k for k in self.chunk_of if k not in self._seen)
-            if cold != self._cold:
-                self._cold = cold
-                self._layout(rebuild=True)
+        # learning step: whoever reported on no rank is "cold"; agreed across ranks once, then frozen
+        if self.overlap and not self._frozen:
+            self._cold = self._agree_cold()
+            self._frozen = True
+            self._layout(rebuild=True)
+
+    def relearn(self):
+        """Forget the readiness layout: the next exchanged backward is a learning step again (no early launches)."""
+        self._cold = frozenset()
+        self._frozen = False
+        if self._arena is not None:
+            self._layout(rebuild=True)
+
+    def _agree_cold(self):
+        """ids of the parameters no rank saw a gradient for in the backward just finished (one small MAX all-reduce; the
+        only host-blocking exchange of the reducer, once per learning step)."""
+        keys = [id(p) for _, p, _, _ in self._arena.entries if p.requires_grad and id(p) in self.chunk_of]
+        mask = torch.tensor([1.0 if k in self._seen else 0.0 for k in keys], dtype=torch.float32)
+        if self.world > 1 or self.force:
+            if self.comm is not None:
+                from . import comm as C
+                dmask = mask.to(self._arena.grad.device)
+                self.comm.all_reduce_async(dmask, C.MAX)
+                self.comm.wait()
+                mask = dmask.cpu()
+            elif dist.is_initialized():
+                dmask = mask.to(self._arena.grad.device) if self._arena.grad.is_cuda else mask
+                dist.all_reduce(dmask, op=dist.ReduceOp.MAX, group=self.group)
+                mask = dmask.cpu()
+        return frozenset(k for k, v in zip(keys, mask.tolist()) if v == 0.0)
 
     def exposed_bytes_last_step(self) -> int:
         """Bytes whose all-reduce could only start in finish() (nothing of backward left to hide it), summed over all steps

@@ -73,6 +73,24 @@ def _worker(rank, world, port, q):
     loss.backward()
     red.finish()
     out["grad_hook"] = arena.grad.clone()
+    # --- frozen readiness layout: parameter 5 reported on no rank in the learning step, so its chunk goes out at
+    # begin_backward(); a gradient for it after that is a change of control flow and must fail loudly
+    out["frozen"] = bool(red._frozen and id(arena.params[5]) in red._cold)
+    arena.grad.zero_()
+    b0, f0 = red.stats["launched_in_backward"], red.stats["launched_in_finish"]
+    red.begin_backward(sync=True)
+    out["early_launches"] = red.stats["launched_in_backward"] - b0
+    try:
+        arena.params[5].grad.add_(1.0); ops.notify_grad_ready([arena.params[5]])
+        out["late_raises"] = False
+    except RuntimeError:
+        out["late_raises"] = True
+    arena.params[5].grad.zero_()
+    for p in reversed(arena.params[:5]):
+        p.grad.add_(float(rank + 1)); ops.notify_grad_ready([p])
+    red.finish()
+    out["finish_launches"] = red.stats["launched_in_finish"] - f0
+    out["grad_frozen"] = arena.grad.clone()
     # by value (numpy), not as shared-memory handles: a handle needs this process alive when the parent unpickles it
     out = {k: (v.numpy() if isinstance(v, torch.Tensor) else [t.numpy() for t in v] if k == "local" else v) for k, v in out.items()}
     q.put(out)
@@ -104,6 +122,12 @@ def test_flat_grad_reducer_gloo_world2():
         exp = torch.zeros(n) if i == 5 else (2 * a["local"][i] + 2 * b["local"][i]).flatten() / 2
         assert torch.allclose(a["grad"][off:off + n], exp, atol=1e-6), i
     assert torch.equal(a["grad_hook"], b["grad_hook"])
+    for o in outs:
+        assert o["frozen"] and o["early_launches"] >= 1 and o["late_raises"] and o["finish_launches"] == 0, \
+            {k: o[k] for k in ("frozen", "early_launches", "late_raises", "finish_launches")}
+    for i, (off, n) in enumerate(a["offsets"]):
+        exp = torch.zeros(n) if i == 5 else torch.full((n,), 1.5)
+        assert torch.allclose(a["grad_frozen"][off:off + n], exp) and torch.equal(a["grad_frozen"], b["grad_frozen"]), i
     for i, (off, n) in enumerate(a["offsets"]):
         exp = torch.full((n,), 1.5) if i < 3 else torch.zeros(n)
         assert torch.allclose(a["grad_hook"][off:off + n], exp), i

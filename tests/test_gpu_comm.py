@@ -131,11 +131,15 @@ def test_reducer_one_rank_equals_local_gradient_and_isolates_cold_parameters(com
         torch.cuda.synchronize()
         assert float((m.arena.grad - local).abs().max()) <= 1e-5 * float(local.abs().max()) + 1e-7, step
         if step == 0:
-            assert red._cold, "high_res_patch_embed never reports a gradient on 64x64 input"
+            assert red._cold and red._frozen, "high_res_patch_embed never reports a gradient on 64x64 input"
+            after_learning = dict(red.stats)
     names = {id(p): n for n, p in m.named_parameters()}
     cold_names = sorted(names[k] for k in red._cold)
     assert cold_names == ["high_res_patch_embed.proj.bias", "high_res_patch_embed.proj.weight"], cold_names
-    # after the first step the cold parameters sit in chunks of their own: only those are launched in finish()
+    # after the learning step the cold parameters sit in chunks of their own, exchanged at begin_backward(): finish() has
+    # nothing left to launch, i.e. no byte of the exchange starts after backward has ended
+    assert red.stats["launched_in_finish"] == after_learning["launched_in_finish"]
+    assert red.stats["bytes_in_finish"] == after_learning["bytes_in_finish"]
     cold_bytes = sum(4 * (e - s) for (s, e), c in zip(red.bounds, red.cold_chunk) if c)
     hot_in_finish = [c for c in range(len(red.bounds)) if not red.cold_chunk[c] and red._remaining[c] > 0]
     assert not hot_in_finish

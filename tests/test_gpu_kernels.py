@@ -554,18 +554,20 @@ def test_attention_optimistic_forward_falls_back(HD, kind):
     assert rel(o, o_ref) < 6e-3
 
 
-@pytest.mark.parametrize("B,N,H,HD", [(2, 5121, 16, 32), (4, 1281, 16, 64)])
-def test_attention_is_bit_reproducible_under_memory_pressure(B, N, H, HD):
-    """Forward, dQ and dK/dV have no atomics, so repeated launches on the same inputs are bit-identical -- also while a
-    second stream saturates HBM and skews the LDS-DMA timing.  Regression screen for ring-slot races (a missing barrier
-    after the pre-loop S_0 made 0.3 % of the decoder-shape launches differ; tools/stress_attn_race.py is the long run)."""
+@pytest.mark.parametrize("B,N,H,HD,fused", [(2, 5121, 16, 32, None), (4, 1281, 16, 64, None), (4, 1281, 16, 64, True),
+                                            (2, 2049, 16, 32, False)])
+def test_attention_is_bit_reproducible_under_memory_pressure(B, N, H, HD, fused):
+    """Forward and every backward form (fused single-pass: the default at head_dim 32; dQ + dK/dV pair: the default at 64) have
+    no atomics, so repeated launches on the same inputs are bit-identical -- also while a second stream saturates HBM and skews
+    the LDS-DMA timing.  Regression screen for ring-slot races (a missing barrier after the pre-loop S_0 made 0.3 % of the
+    decoder-shape launches differ; tools/stress_attn_race.py is the long run)."""
     g = torch.Generator().manual_seed(3)
     qkv = bf(torch.randn(B * N, 3 * H * HD, generator=g)).to(DEV)
     do = bf(torch.randn(B * N, H * HD, generator=g)).to(DEV)
     scale = HD ** -0.5
     o0, lse0 = ops.attn_fwd(qkv, B, N, H, HD, scale)
     os0, lses0 = ops.attn_fwd(qkv, B, N, H, HD, scale, optimistic=False)
-    d0 = ops.attn_bwd(qkv, o0, do, lse0, B, N, H, HD, scale)
+    d0 = ops.attn_bwd(qkv, o0, do, lse0, B, N, H, HD, scale, fused=fused)
     side = torch.cuda.Stream()
     junk = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=DEV)
     bad = torch.zeros((), dtype=torch.int32, device=DEV)
@@ -579,7 +581,7 @@ def test_attention_is_bit_reproducible_under_memory_pressure(B, N, H, HD):
             o, lse = ops.attn_fwd(qkv, B, N, H, HD, scale, optimistic=False)
             bad += (o != os0).any().int() + (lse != lses0).any().int()
         if it % 4 == 2:
-            d = ops.attn_bwd(qkv, o0, do, lse0, B, N, H, HD, scale)
+            d = ops.attn_bwd(qkv, o0, do, lse0, B, N, H, HD, scale, fused=fused)
             bad += (d != d0).any().int()
     torch.cuda.synchronize()
     assert int(bad) == 0
