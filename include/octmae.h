@@ -23,7 +23,7 @@ extern "C" {
 /* The ONE place the ABI number lives: octmae_abi_version() returns it (csrc/probe.hip), octcubem_amd/_lib.py parses it
  * from this header and refuses a library that reports another number, __graft_entry__.build() and the tests compare the two.
  * 4: octmae_attn_bwd_dq_rowconst.  5: octmae_comm_* (RCCL), octmae_attn_bwd_fused + workspace query. */
-#define OCTMAE_ABI_VERSION 5
+#define OCTMAE_ABI_VERSION 6
 int octmae_abi_version(void);
 
 /* ---- GEMM with fused epilogues ------------------------------------------------------------------
@@ -42,6 +42,19 @@ int octmae_abi_version(void);
 int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
                      int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided, int b_kstrided,
                      int epilogue, int splitk, void* stream);
+
+/* Backward of epilogue 2 together with fc1's bias gradient, WITHOUT atomics (timm Mlp backward: fc2 dgrad, nn.GELU backward,
+ * fc1.bias.grad; video_vit.py:174-179 under autograd):
+ *   dX bf16 [M][K] = (dY[M][N] @ W[N][K]) * gelu'(pre[M][K]),   bias_grad[K] += column sums of dX   (bias_grad may be NULL).
+ * Every 64-row slab of dX leaves its column sums as one row of `ws` (fp32 [octmae_dgelu_colsum_ws_rows(M)][K], caller-owned,
+ * need not be initialised) with plain stores; a second launch (octmae_colsum_accum over `ws`) folds the rows into bias_grad:
+ * at most 128 atomic adds per address instead of one per 64-row slab -- thousands of slabs adding to one [K] vector serialise
+ * per address (~60 ns each: +0.67 ms on the decoder's fc2 at micro-batch 128, +0.13 ms on the encoder's).  Same result as
+ * octmae_gemm_bf16(epilogue 4) up to the order of the fp32 additions.  Problems too small for the 256-tile kernel ignore `ws`
+ * and sum the columns of dX in a separate pass.  small_tile: kernel-selection bits as in octmae_linear_resid_rowscale, 0 = automatic. */
+int octmae_dgelu_colsum_ws_rows(int M);
+int octmae_linear_dgrad_dgelu(const void* W, const void* dY, void* dX, const void* pre, float* ws, float* bias_grad,
+                              int M, int N, int K, int ldw, int ldy, int ldx, int ldpre, int small_tile, void* stream);
 
 /* Stochastic depth (timm DropPath around both Block branches, video_vit.py:181-184 with drop_path > 0; fine-tune drivers use
  * 0.1-0.2): out f32 [M][N] = res + rowscale[m / rows_per_scale] * (X[M][K] @ W[N][K]^T + bias) -- the per-sample keep mask

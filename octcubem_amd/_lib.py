@@ -33,6 +33,8 @@ SIGNATURES = {
     "octmae_cast_rowscale_f32_bf16": [_vp, _vp, _vp, _ll, _i, _i, _vp],
     "octmae_linear_resid_rowscale": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "octmae_colsum_accum": [_vp, _i, _vp, _i, _i, _i, _vp],
+    "octmae_dgelu_colsum_ws_rows": [_i],
+    "octmae_linear_dgrad_dgelu": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "octmae_patch_gather": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "octmae_enc_assemble": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "octmae_dec_assemble": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -50,6 +50,8 @@ struct GemmParams {
   const float* rowscale;   // EPI_RESID only: C = aux + rowscale[b / rows_per_scale] * (X + bias)   (stochastic depth); NULL = 1
   int rows_per_scale;
   int cgroup;              // 256-tile kernels: column tiles (a) per group of the tile order, see tile_coord()
+  int ldc2;                // EPI_DGELU column sums: 0 = C2 is an fp32 [NA] vector (atomics); > 0 = C2 is fp32 [NB / 64][ldc2],
+                           // one row of partial sums per 64-row slab, plain stores (folded by a second launch)
 };
 
 // Tile order of the 256-tile kernels.  xcd_remap hands every XCD one contiguous range of t.  Inside a group of `cgroup`
@@ -437,10 +439,21 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
         float* colsum = reinterpret_cast<float*>(p.C2);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float t = cs[e];
-          t += __shfl_xor(t, 16, 64);
-          t += __shfl_xor(t, 32, 64);
-          if (rrow == 0 && a_ok) unsafeAtomicAdd(colsum + a + e, t);
+          cs[e] += __shfl_xor(cs[e], 16, 64);
+          cs[e] += __shfl_xor(cs[e], 32, 64);
+        }
+        if (p.ldc2 > 0) {
+          // one row of partial sums per 64-row slab, 512 contiguous bytes per wave, plain stores: thousands of row slabs adding
+          // to the SAME [NA] vector with atomics serialise in the L2 (~60 ns per add and address: +0.67 ms on the decoder's fc2 dgrad)
+          if (rrow == 0 && a_ok) {
+            float* dst = colsum + (size_t)(b_base >> 6) * p.ldc2 + a;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (rrow == 0 && a_ok) unsafeAtomicAdd(colsum + a + e, cs[e]);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -851,7 +864,8 @@ extern "C" int octmae_colsum_accum(const void* in, int in_is_bf16, float* out, i
 // C[b][a] (+epilogue) = sum_k A[a][k] B[b][k];  see include/octmae.h for the contract.
 static int gemm_impl(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
                      int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided,
-                     int b_kstrided, int epilogue, int splitk, void* stream, const float* rowscale, int rows_per_scale) {
+                     int b_kstrided, int epilogue, int splitk, void* stream, const float* rowscale, int rows_per_scale,
+                     float* colsum_ws = nullptr) {
   // bit 8 of `epilogue` forces the 128-tile kernel, bit 9 the two-stage (un-phased) 256-tile main loop: tests and A/B runs
   // exercise every kernel on the same problem
   const int variant = (epilogue >> 8) & 1;
@@ -920,11 +934,16 @@ static int gemm_impl(const void* A, const void* B, void* C, void* C2, const floa
   // stand-alone column-sum kernel.
   float* dgelu_colsum = (epilogue == EPI_DGELU) ? reinterpret_cast<float*>(C2) : nullptr;
   if (epilogue == EPI_DGELU && !(big && (NA & 7) == 0)) p.C2 = nullptr;
+  p.ldc2 = 0;
+  const int ws_rows = 4 * p.tiles_b;             // 64-row slabs of the 256-tile grid
+  if (epilogue == EPI_DGELU && p.C2 != nullptr && colsum_ws != nullptr) { p.C2 = colsum_ws; p.ldc2 = NA; }
 #define OCTMAE_GEMM_CASE(AKS, BKS, E, AB)                                  \
   if (a_kstrided == AKS && b_kstrided == BKS && epilogue == E) {           \
     int rc_ = big ? launch256<AKS, BKS, E, AB>(p, splitk, st, phased) : launch<AKS, BKS, E, AB>(p, splitk, st);          \
     if (rc_ == 0 && E == EPI_DGELU && dgelu_colsum != nullptr && p.C2 == nullptr)                                       \
       rc_ = octmae_colsum_accum(C, 1, dgelu_colsum, NB, NA, ldc, stream);                                                \
+    if (rc_ == 0 && E == EPI_DGELU && dgelu_colsum != nullptr && p.ldc2 > 0)                                             \
+      rc_ = octmae_colsum_accum(colsum_ws, 0, dgelu_colsum, ws_rows, NA, NA, stream);                                     \
     return rc_;                                                                                                           \
   }
   // forward linears (nn.Linear layout both sides)
@@ -955,4 +974,13 @@ extern "C" int octmae_linear_resid_rowscale(const void* W, const void* X, float*
   OCTMAE_CHECK_ARG(rowscale != nullptr && rows_per_scale > 0);
   return gemm_impl(W, X, out, nullptr, bias, res, N, M, K, ldw, ldx, ldout, ldres, 0, 0, EPI_RESID | (small_tile & 0x700), 1,
                    stream, rowscale, rows_per_scale);
+}
+
+extern "C" int octmae_dgelu_colsum_ws_rows(int M) { return M > 0 ? 4 * ((M + T2 - 1) / T2) : 0; }
+
+extern "C" int octmae_linear_dgrad_dgelu(const void* W, const void* dY, void* dX, const void* pre, float* ws, float* bias_grad,
+                                         int M, int N, int K, int ldw, int ldy, int ldx, int ldpre, int small_tile, void* stream) {
+  OCTMAE_CHECK_ARG(bias_grad == nullptr || ws != nullptr);
+  return gemm_impl(W, dY, dX, bias_grad, nullptr, pre, K, M, N, ldw, ldy, ldx, ldpre, 1, 0, EPI_DGELU | (small_tile & 0x700), 1, stream, nullptr, 1,
+                   bias_grad != nullptr ? ws : nullptr);
 }

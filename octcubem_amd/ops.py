@@ -208,17 +208,30 @@ def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], m
 
 
 def linear_dgrad(dy: torch.Tensor, w: torch.Tensor, pre: Optional[torch.Tensor] = None,
-                 colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 colsum: Optional[torch.Tensor] = None, atomic_colsum: bool = False) -> torch.Tensor:
     """dx[M,K] = dy[M,N] @ w[N,K]  (optionally * gelu'(pre[M,K])), bf16.  With ``pre``, ``colsum`` (fp32 [K]) receives
-    += the column sums of dx -- the bias gradient of the Linear that produced ``pre`` -- from the same kernel."""
+    += the column sums of dx -- the bias gradient of the Linear that produced ``pre`` -- from the same call: per-slab partial
+    sums through a workspace and a folding launch (octmae_linear_dgrad_dgelu); ``atomic_colsum`` selects the
+    fp32-atomic form of octmae_gemm_bf16's epilogue 4 instead (kept for comparison)."""
     M, N = dy.shape
     K = w.shape[1]
     dx = torch.empty((M, K), dtype=BF16, device=dy.device)
     if pre is None:
         assert colsum is None
         _gemm(w, dy, dx, K, M, N, w.stride(0), dy.stride(0), K, 1, 0, EPI_BF16)
-    else:
+    elif colsum is None or atomic_colsum:
         _gemm(w, dy, dx, K, M, N, w.stride(0), dy.stride(0), K, 1, 0, EPI_DGELU, C2=colsum, aux=pre, ldaux=pre.stride(0))
+    else:
+        from ._lib import load
+        rows = load().octmae_dgelu_colsum_ws_rows(M)
+        ws = torch.empty((rows, K), dtype=F32, device=dy.device)
+        args = (w.data_ptr(), dy.data_ptr(), dx.data_ptr(), pre.data_ptr(), ws.data_ptr(), colsum.data_ptr(), M, N, K, w.stride(0),
+                dy.stride(0), K, pre.stride(0), _variant_bits(), _stream())
+        if KTIMER is None:
+            call("octmae_linear_dgrad_dgelu", *args)
+        else:   # two launches (GEMM + the fold of the partial sums), timed together
+            KTIMER.launch("gemm_dgrad_epi4", 2.0 * K * M * N, 2.0 * (K * N + M * N) + 2.0 * K * M,
+                          lambda: call("octmae_linear_dgrad_dgelu", *args))
     return dx
 
 

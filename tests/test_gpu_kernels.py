@@ -184,9 +184,12 @@ def test_gemm_dgrad_and_wgrad(M, N, K, tile_variant):
     assert rel(dxg, xg.grad) < 3e-3
     cs0 = torch.randn(K, generator=g).to(DEV)                # fused column sums (fc1 bias gradient) accumulate into a vector
     cs = cs0.clone()
-    dxg2 = ops.linear_dgrad(dy, w, pre=pre, colsum=cs)
+    dxg2 = ops.linear_dgrad(dy, w, pre=pre, colsum=cs)     # octmae_linear_dgrad_dgelu: per-slab partial sums in a workspace + fold
     assert torch.equal(dxg2, dxg)
     assert rel(cs, cs0.double() + dxg.double().sum(0)) < 2e-5
+    cs_at = cs0.clone()                                     # epilogue 4 of octmae_gemm_bf16 with a C2 vector: fp32 atomics
+    dxg3 = ops.linear_dgrad(dy, w, pre=pre, colsum=cs_at, atomic_colsum=True)
+    assert torch.equal(dxg3, dxg) and rel(cs_at, cs0.double() + dxg.double().sum(0)) < 2e-5
     gw0 = torch.randn(N, K, generator=g).to(DEV)
     gw = gw0.clone()
     ops.linear_wgrad_accum(dy, x, gw)

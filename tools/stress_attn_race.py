@@ -1,5 +1,6 @@
 """Race screen for the LDS-DMA attention kernels: forward, dQ and dK/dV are deterministic (no atomics), so repeated launches on
-the same inputs must be BIT-identical, also while another stream hammers HBM/L2 to perturb the DMA timing."""
+the same inputs must be BIT-identical (the fused single-pass backward included: its dQ workspace is summed by the same lane in
+program order), also while another stream hammers HBM/L2 to perturb the DMA timing."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from octcubem_amd import ops
@@ -10,8 +11,8 @@ cases = []
 for (B, N, H, HD) in ((4, 1281, 16, 64), (2, 5121, 16, 32), (3, 200, 4, 64), (3, 333, 4, 32)):
     qkv = torch.randn(B * N, 3 * H * HD, device="cuda").to(torch.bfloat16); do = torch.randn(B * N, H * HD, device="cuda").to(torch.bfloat16)
     o, lse = ops.attn_fwd(qkv, B, N, H, HD, HD ** -0.5)
-    dq = ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, HD ** -0.5)
-    cases.append((B, N, H, HD, qkv, do, o.clone(), lse.clone(), dq.clone()))
+    dq = {f: ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, HD ** -0.5, fused=f).clone() for f in (True, False)}   # both backward forms
+    cases.append((B, N, H, HD, qkv, do, o.clone(), lse.clone(), dq))
 bad = 0; n = 0; t0 = time.time()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 while time.time() - t0 < budget:
@@ -24,9 +25,10 @@ while time.time() - t0 < budget:
                 n += 2
                 if not (torch.equal(o, o0) and torch.equal(lse, lse0)):
                     bad += 1; print("FWD MISMATCH", (B, N, H, HD), flush=True)
-        dq = ops.attn_bwd(qkv, o0, do, lse0, B, N, H, HD, HD ** -0.5)
-        n += 1
-        if not torch.equal(dq, dq0):
-            bad += 1; print("BWD MISMATCH", (B, N, H, HD), float((dq.float() - dq0.float()).abs().max()), flush=True)
+        for f in (True, False):
+            dq = ops.attn_bwd(qkv, o0, do, lse0, B, N, H, HD, HD ** -0.5, fused=f)
+            n += 1
+            if not torch.equal(dq, dq0[f]):
+                bad += 1; print("BWD MISMATCH", (B, N, H, HD), "fused" if f else "pair", float((dq.float() - dq0[f].float()).abs().max()), flush=True)
 torch.cuda.synchronize()
 print(f"{n} comparisons, {bad} mismatches in {time.time() - t0:.0f} s")
