@@ -35,6 +35,9 @@ __device__ __forceinline__ f32x4_t mfma16(bf16x8 a, bf16x8 b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+#ifndef BWD_DMA_MID
+#define BWD_DMA_MID(HD) ((HD) == 64)
+#endif
 #ifdef BWD_STAMP
 // diagnostic build only: per-wave cycle sums of the tile loop's segments (never read by the kernel itself)
 __device__ unsigned long long g_bwd_stamp[512 * 8 * 8];
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
     };
     // units(t): S / dP / P / dS of tile t against this wave's keys, dS -> image t % NIMG, dV^T / dK^T accumulate.  Per 32-query
     // sub-tile the row constants and the Q / dO fragments are read ONCE and shared by the wave's key groups.
-    auto units = [&](int t) {
+    auto units = [&](int t, auto&& between) {
       const int slot = t % NB;
       const char* cQ = smem + C::QR + slot * T::BYTES;
       const char* cO = smem + C::OR_ + slot * T::BYTES;
@@ -411,6 +414,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
             }
           }
         }
+        if (u == 0) between();
       }
     };
     // dqmul(tq): this wave's dQ^T tiles of tile tq over its KH keys of the image -> acc0 / acc1; PAIR: the tile this wave
@@ -440,11 +444,21 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
     unsigned long long tlast = stamp();
 #endif
     for (int t = 0; t < ntiles; ++t) {
-      if (t > 0) finish(t - 1, ICD{});
-      oldreq(t);
-      issue(t + 2);
-      STAMP(0);
-      units(t);
+      // Where the tile's memory requests go.  head_dim 64: between the two sub-tiles of `units` -- issued among VALU work an
+      // LDS-DMA piece costs 25-60 cycles, in a segment of their own 100-185 (MI355X_MICROARCH.md): same-box 6.18 -> 5.65 ms
+      // (16 x 16 x 5121 x 64).  head_dim 32, whose units are VALU-bound already, keeps them at the head of the tile (neutral
+      // there, and 6 more spilled registers).  Moving finish(t-1) there as well: 10 spilled registers at head_dim 64, +10 % time.
+      if (BWD_DMA_MID(HD)) {
+        if (t > 0) finish(t - 1, ICD{});
+        STAMP(0);
+        units(t, [&]() { oldreq(t); issue(t + 2); });
+      } else {
+        if (t > 0) finish(t - 1, ICD{});
+        oldreq(t);
+        issue(t + 2);
+        STAMP(0);
+        units(t, []() {});
+      }
       STAMP(1);
       wait_lgkm0();
       __builtin_amdgcn_s_barrier();               // A: the image of tile t is complete
