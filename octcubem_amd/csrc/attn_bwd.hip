@@ -105,6 +105,21 @@ __device__ __forceinline__ int img_sw(int row) {
 // byte offset of the 8-byte chunk c8 (4 queries) of key row `row` in a dS image (128-byte rows = 64 queries)
 __device__ __forceinline__ int img_off(int row, int c8) { return row * 128 + ((c8 ^ img_sw(row)) << 3); }
 
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+// LDS accesses by byte OFFSET (address space 3 stated explicitly: pointer arithmetic through integers would otherwise come
+// back as generic pointers and flat_load / flat_store)
+#define OCTMAE_LDS_PTR(T, off) (reinterpret_cast<__attribute__((address_space(3))) T*>((__attribute__((address_space(3))) char*)(size_t)(off)))
+template <class T>
+__device__ __forceinline__ T lds_ld(unsigned off) { return *OCTMAE_LDS_PTR(const T, off); }
+template <class T>
+__device__ __forceinline__ void lds_st(unsigned off, T v) { *OCTMAE_LDS_PTR(T, off) = v; }
+__device__ __forceinline__ bf16x4 lds_tr_ld(unsigned off) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(OCTMAE_LDS_PTR(bf16x4, off));
+}
+
 // s_waitcnt vmcnt(CNT) -- the CNT youngest vector-memory operations of this wave stay in flight
 template <int CNT>
 __device__ __forceinline__ void wait_vm() {
@@ -194,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
   using C = BwdCfg<HD>;
   using T = typename C::T;
   constexpr int KS = C::KS, DB = C::DB, NG = C::NG, NB = C::NB, PD = C::PD, NT = C::NT;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(128))) char smem[];    // 128: the XOR chunk selectors below act on address bits 0..6
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -266,6 +281,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
   const int p2row = khalf * C::KH + 8 * kg + q4;
   const int p2a0 = C::IMG + p2row * 128 + (((8 * qpair + p4) ^ img_sw((8 * kg + q4) & 15)) << 3);
   const int p2a1 = C::IMG + (p2row + 4) * 128 + (((8 * qpair + p4) ^ img_sw((8 * kg + q4 + 4) & 15)) << 3);
+
+  // ---- per-lane address parts of `units` (byte offsets into the LDS, fixed for the whole kernel; `opaque` keeps the compiler
+  // from re-deriving them from the lane id inside the tile loop).  T::sw() reads row bits 1..3 only, so neither the sub-tile
+  // (+32 rows) nor the k-step of a transposed read (+16 rows) changes a swizzle.
+  static_assert((T::BYTES % 128) == 0 && ((32 * T::ROWB) % 128) == 0 && (C::IMG % 128) == 0 && (C::IMG_BYTES % 128) == 0 && (C::CR % 128) == 0,
+                "slot / sub-tile / region offsets must leave the low 7 address bits alone (XOR chunk selectors)");
+  const int tq_ = (lane >> 2) & 3, tp_ = lane & 3, tgi = (lane >> 4) & 1;
+  const unsigned a_const = opaque(lds0 + (unsigned)(C::CR + 16 * h));                                   // row constants: + 32 G (+ 256: delta)
+  const unsigned a_row = opaque(lds0 + (unsigned)(C::QR + T::off(r, h)));                                // row fragment, k-step 0
+  const unsigned a_trlo = opaque(lds0 + (unsigned)(C::QR + T::off(4 * h + tq_, 2 * tgi + (tp_ >> 1)) + (tp_ & 1) * 8));
+  const unsigned a_trhi = opaque(lds0 + (unsigned)(C::QR + T::off(4 * h + tq_ + 8, 2 * tgi + (tp_ >> 1)) + (tp_ & 1) * 8));
+  const unsigned a_img = opaque(lds0 + (unsigned)(C::IMG + img_off(wid * C::KW + r, h)));               // dS image, chunk h of this lane's key row
 
   for (int kb = 0; kb < nkb; ++kb) {
     const int key0 = kb * C::KB;
@@ -357,32 +384,39 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
     // sub-tile the row constants and the Q / dO fragments are read ONCE and shared by the wave's key groups.
     auto units = [&](int t, auto&& between) {
       const int slot = t % NB;
-      const char* cQ = smem + C::QR + slot * T::BYTES;
-      const char* cO = smem + C::OR_ + slot * T::BYTES;
-      const float* cC = reinterpret_cast<const float*>(smem + C::CR + slot * 512);
-      char* img = smem + C::IMG + (t % C::NIMG) * C::IMG_BYTES;
 #pragma unroll 1
       for (int u = 0; u < 2; ++u) {
+        // Addresses: every per-lane part is one of the kernel-lifetime values a_* (see their definition); what varies here --
+        // ring slot and sub-tile -- is a multiple of 128 bytes and goes in with ONE add per address family, the k-step / head-dim
+        // block / query-chunk selectors are XOR masks below 128 or immediate offsets.  (Left to the compiler this block took 38
+        // address instructions per sub-tile in a loop that is bound by vector issue.)
+        const unsigned X = (unsigned)(slot * T::BYTES + u * 32 * T::ROWB);
+        const unsigned pc = a_const + (unsigned)(slot * 512 + u * 128);
+        const unsigned prow = a_row + X, ptl = a_trlo + X, pth = a_trhi + X;
+        const unsigned pw = (a_img + (unsigned)((t % C::NIMG) * C::IMG_BYTES)) ^ (unsigned)(u * 64);
         f32x16 lse_t, dlt_t;                      // row constants: register 4G+e <-> query row 32u + 8G + 4h + e
 #pragma unroll
         for (int G = 0; G < 4; ++G) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(cC + 32 * u + 8 * G + 4 * h);
-          const f32x4 d = *reinterpret_cast<const f32x4*>(cC + 64 + 32 * u + 8 * G + 4 * h);
+          const f32x4 a = lds_ld<f32x4>(pc + 32 * G);
+          const f32x4 d = lds_ld<f32x4>(pc + 256 + 32 * G);
 #pragma unroll
           for (int e = 0; e < 4; ++e) { lse_t[4 * G + e] = a[e]; dlt_t[4 * G + e] = d[e]; }
         }
         bf16x8 qrow[KS], orow[KS], qT[2][DB], oT[2][DB];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          qrow[s] = T::row_frag(cQ, 32 * u, s, lane);
-          orow[s] = T::row_frag(cO, 32 * u, s, lane);
+        for (int s = 0; s < KS; ++s) {            // T::row_frag(tile, 32 u, s): chunk 2 s + h  ->  address ^ 32 s
+          const unsigned pr = prow ^ (unsigned)(32 * s);
+          qrow[s] = lds_ld<bf16x8>(pr);
+          orow[s] = lds_ld<bf16x8>(pr + (C::OR_ - C::QR));
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-          for (int d = 0; d < DB; ++d) {
-            qT[s][d] = T::tr_frag(cQ, 32 * u, s, 32 * d, lane);
-            oT[s][d] = T::tr_frag(cO, 32 * u, s, 32 * d, lane);
+          for (int d = 0; d < DB; ++d) {          // T::tr_frag(tile, 32 u, s, 32 d): rows + 16 s (immediate), chunk + 4 d -> ^ 64 d
+            const unsigned pl = (ptl ^ (unsigned)(64 * d)) + s * 16 * T::ROWB;
+            const unsigned ph = (pth ^ (unsigned)(64 * d)) + s * 16 * T::ROWB;
+            qT[s][d] = cat4(lds_tr_ld(pl), lds_tr_ld(ph));
+            oT[s][d] = cat4(lds_tr_ld(pl + (C::OR_ - C::QR)), lds_tr_ld(ph + (C::OR_ - C::QR)));
           }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -398,15 +432,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
             sa[e] = p;
             dp[e] = p * dp[e];                    // dS / scale
           }
-          const int krow = wid * C::KW + 32 * g + r;
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
             const bf16x8 pf = acc_to_frag(sa, s);
             const bf16x8 dsf = acc_to_frag(dp, s);
             const u32x4 w = __builtin_bit_cast(u32x4, dsf);
-            // registers 8s..8s+3 <-> queries 32u + 16s + 4h + 0..3 ; 8s+4..8s+7 <-> 32u + 16s + 8 + 4h + 0..3
-            *reinterpret_cast<u32x2*>(img + img_off(krow, 8 * u + 4 * s + h)) = u32x2{w[0], w[1]};
-            *reinterpret_cast<u32x2*>(img + img_off(krow, 8 * u + 4 * s + 2 + h)) = u32x2{w[2], w[3]};
+            // registers 8s..8s+3 <-> queries 32u + 16s + 4h + 0..3 ; 8s+4..8s+7 <-> 32u + 16s + 8 + 4h + 0..3: image chunk
+            // 8 u + 4 s + 2 k + h of key row wid * KW + 32 g + r  ->  address ^ (32 s + 16 k), + 32 g rows (immediate)
+            lds_st<u32x2>((pw ^ (unsigned)(32 * s)) + g * 32 * 128, u32x2{w[0], w[1]});
+            lds_st<u32x2>((pw ^ (unsigned)(32 * s + 16)) + g * 32 * 128, u32x2{w[2], w[3]});
 #pragma unroll
             for (int d = 0; d < DB; ++d) {
               dv[g][d] = mfma32(oT[s][d], pf, dv[g][d]);

@@ -288,9 +288,10 @@ def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, HD: int, scale: float, o
 
 
 # Which backward runs per head_dim: the single-pass kernel (csrc/attn_bwd.hip) or the dQ + dK/dV kernel pair (csrc/attn.hip).
-# Measured on MI355X (tools/attn_bwd_ab.py, same process, interleaved): head_dim 32 (decoder, N = 5121) fused 4-6 % faster,
-# head_dim 64 (encoder N = 1281, fine-tune N = 5121) the pair 10-13 % faster -- the fused form is limited by LDS traffic there.
-ATTN_BWD_FUSED = {32: True, 64: False}
+# Measured on MI355X (tools/attn_bwd_ab.py, same process, interleaved): head_dim 32 (decoder, N = 5121) fused 11 % faster;
+# head_dim 64 fused 4 % faster at N = 1281 (encoder) and 2 % at N = 5121 (fine-tune) since its LDS-DMA requests go out between
+# the sub-tiles and its sub-tile addressing is hand-placed (before: the pair 10-13 % faster).
+ATTN_BWD_FUSED = {32: True, 64: True}
 
 
 def attn_bwd(qkv, o, dout, lse, B, N, H, HD, scale, fused: Optional[bool] = None):
