@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : ATT_OCC_FWD64)) vo
   constexpr int KS = HD / 16;   // k-steps over the head dimension
   constexpr int DB = HD / 32;   // 32-wide blocks of the head dimension
   using T = Tile<HD>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // LDS: K0 K1 V0 V1
+  extern __shared__ __attribute__((aligned(128))) char smem[];   // 128: XOR chunk selectors act on address bits 0..6
+  // LDS: K ring | V ring
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -128,22 +128,36 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : ATT_OCC_FWD64)) vo
   for (int s = -NB; s < 0; ++s) issue(s + NB, s + NB - 1);
   dma_wait_barrier<DMA_CNT>();             // K_0, K_1, V_0 landed and visible
 
-  auto qk = [&](const char* cK, f32x16 (&sa)[2]) {
+  // Hand-placed LDS addressing (attn_tile.hpp): the per-lane parts of T::row_frag / T::tr_frag are fixed for the kernel, the
+  // ring slot goes in with one add per family, k-step / head-dim block are XOR masks below 128 or immediate offsets
+  // (T::sw() reads row bits 1..3 only: +32 and +16 rows leave the swizzle alone).  Left to the compiler the hd-64 loop spent
+  // 45 of its 205 instructions on these addresses.
+  static_assert(T::BYTES % 128 == 0, "ring slots must leave the low 7 address bits alone");
+  const int tq_ = (lane >> 2) & 3, tp_ = lane & 3, tgi = (lane >> 4) & 1;
+  constexpr bool HAND = (HD == 64);     // head_dim 32 runs at the 168-register limit of 3 waves per SIMD: three more live values spill in its loop
+  const unsigned a_row = !HAND ? 0u : opaque(lds0 + (unsigned)T::off(r, h));                                          // K row fragment, k-step 0
+  const unsigned a_trlo = !HAND ? 0u : opaque(lds0 + (unsigned)(NB * T::BYTES + T::off(4 * h + tq_, 2 * tgi + (tp_ >> 1)) + (tp_ & 1) * 8));   // V^T
+  const unsigned a_trhi = !HAND ? 0u : opaque(lds0 + (unsigned)(NB * T::BYTES + T::off(4 * h + tq_ + 8, 2 * tgi + (tp_ >> 1)) + (tp_ & 1) * 8));
+  auto qk = [&](int tk, f32x16 (&sa)[2]) {                      // S^T of key tile tk
     // row constant -m_s as the initial accumulator (a persistent 16-register tile of it would save the broadcast but
     // pushes the kernel past the 168-VGPR budget of 3 waves per SIMD: measured 2.4x slower from spills)
     const float neg_m = FAST ? 0.f : -m_s;                      // FAST: literal 0 -> the MFMA's inline-constant C operand
+    const unsigned pk = a_row + (unsigned)((tk % NB) * T::BYTES);
+    const char* cK = Kbuf + (tk % NB) * T::BYTES;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) sa[kb][g] = neg_m;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) sa[kb] = mfma32(T::row_frag(cK, kb * 32, s, lane), qf[s], sa[kb]);
+      for (int s = 0; s < KS; ++s)
+        sa[kb] = mfma32(HAND ? lds_ld<bf16x8>((pk ^ (unsigned)(32 * s)) + kb * 32 * T::ROWB) : T::row_frag(cK, kb * 32, s, lane), qf[s], sa[kb]);
     }
   };
 
   // tile t: scur = S_t (already computed), snext <- S_{t+1}
   auto step = [&](int t, f32x16 (&scur)[2], f32x16 (&snext)[2], auto last_tag) {
     constexpr bool last = decltype(last_tag)::value;             // compile-time: the masking code must not leak into the loop
+    const unsigned pvl = a_trlo + (unsigned)((t % NB) * T::BYTES), pvh = a_trhi + (unsigned)((t % NB) * T::BYTES);
     const char* cV = Vbuf + (t % NB) * T::BYTES;
     issue(t + NB, t + NB - 1);
     if (last) {                                                  // only the last tile can hold keys >= N
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : ATT_OCC_FWD64)) vo
       }
     }
     const bool alias = (&scur[0] == &snext[0]);
-    if (!last && !alias) qk(Kbuf + ((t + 1) % NB) * T::BYTES, snext);     // MFMA pipe works on S_{t+1} under the exps below
+    if (!last && !alias) qk(t + 1, snext);     // MFMA pipe works on S_{t+1} under the exps below
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -200,10 +214,14 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : ATT_OCC_FWD64)) vo
       for (int s = 0; s < 2; ++s) {
         const bf16x8 pf = acc_to_frag(scur[kb], s);
 #pragma unroll
-        for (int d = 0; d < DB; ++d) oacc[d] = mfma32(T::tr_frag(cV, kb * 32, s, d * 32, lane), pf, oacc[d]);
+        for (int d = 0; d < DB; ++d) {           // T::tr_frag(V tile, 32 kb, s, 32 d)
+          const unsigned ro = (unsigned)((kb * 32 + s * 16) * T::ROWB);
+          oacc[d] = mfma32(HAND ? cat4(lds_tr_ld((pvl ^ (unsigned)(64 * d)) + ro), lds_tr_ld((pvh ^ (unsigned)(64 * d)) + ro))
+                                : T::tr_frag(cV, kb * 32, s, d * 32, lane), pf, oacc[d]);
+        }
         if (ONES_SUM) lacc = mfma32(ones, pf, lacc);
       }
-    if (!last && alias) qk(Kbuf + ((t + 1) % NB) * T::BYTES, snext);
+    if (!last && alias) qk(t + 1, snext);
     dma_wait_barrier<DMA_CNT>();
   };
 
@@ -220,7 +238,7 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : ATT_OCC_FWD64)) vo
     return;
   }
   f32x16 sA[2], sB[2];
-  qk(Kbuf, sA);
+  qk(0, sA);
   // S_0 is the only score tile computed outside a step: step 0 restages slot 0 of the K ring (K_NB) right away, so every
   // wave's reads of K_0 must have returned first (found by tools/stress_attn_race.py: without this barrier 0.3 % of the
   // decoder-shape launches differed in a few rows)

@@ -105,21 +105,6 @@ __device__ __forceinline__ int img_sw(int row) {
 // byte offset of the 8-byte chunk c8 (4 queries) of key row `row` in a dS image (128-byte rows = 64 queries)
 __device__ __forceinline__ int img_off(int row, int c8) { return row * 128 + ((c8 ^ img_sw(row)) << 3); }
 
-__device__ __forceinline__ unsigned opaque(unsigned v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
-// LDS accesses by byte OFFSET (address space 3 stated explicitly: pointer arithmetic through integers would otherwise come
-// back as generic pointers and flat_load / flat_store)
-#define OCTMAE_LDS_PTR(T, off) (reinterpret_cast<__attribute__((address_space(3))) T*>((__attribute__((address_space(3))) char*)(size_t)(off)))
-template <class T>
-__device__ __forceinline__ T lds_ld(unsigned off) { return *OCTMAE_LDS_PTR(const T, off); }
-template <class T>
-__device__ __forceinline__ void lds_st(unsigned off, T v) { *OCTMAE_LDS_PTR(T, off) = v; }
-__device__ __forceinline__ bf16x4 lds_tr_ld(unsigned off) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(OCTMAE_LDS_PTR(bf16x4, off));
-}
-
 // s_waitcnt vmcnt(CNT) -- the CNT youngest vector-memory operations of this wave stay in flight
 template <int CNT>
 __device__ __forceinline__ void wait_vm() {

@@ -35,6 +35,23 @@ struct Tile {  // 64 rows x HD bf16, row-major, XOR-swizzled 16-byte chunks
   }
 };
 
+// ---- hand-placed LDS addressing (attn_bwd.hip `units`, attn.hip forward): per-lane byte offsets computed once, kept opaque so
+// that the compiler does not re-derive them from the lane id inside the loops, and dereferenced as address-space-3 pointers
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+// LDS accesses by byte OFFSET (address space 3 stated explicitly: pointer arithmetic through integers would otherwise come
+// back as generic pointers and flat_load / flat_store)
+#define OCTMAE_LDS_PTR(T, off) (reinterpret_cast<__attribute__((address_space(3))) T*>((__attribute__((address_space(3))) char*)(size_t)(off)))
+template <class T>
+__device__ __forceinline__ T lds_ld(unsigned off) { return *OCTMAE_LDS_PTR(const T, off); }
+template <class T>
+__device__ __forceinline__ void lds_st(unsigned off, T v) { *OCTMAE_LDS_PTR(T, off) = v; }
+__device__ __forceinline__ bf16x4 lds_tr_ld(unsigned off) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(OCTMAE_LDS_PTR(bf16x4, off));
+}
+
 // (query/key block, head, batch) of this workgroup.  The hardware hands consecutive linear block ids to the 8 XCDs round
 // robin, so with the plain (x, y, z) mapping the ~N/128 workgroups that share one (batch, head)'s K/V land on all 8 XCDs and
 // every XCD's L2 fetches those K/V separately (measured: 5.5x the algorithmic HBM bytes).  xcd_remap gives each XCD a
