@@ -38,6 +38,8 @@ int octmae_abi_version(void);
  *                                                 vector that receives += the column sums of C (fc1's bias gradient)
  *   5  C f32[a][b] += X  (NA rows x NB columns; split-K over `splitk` workgroup slices, fp32 atomics
  *                         when splitk > 1)        weight gradients (autograd of nn.Linear)
+ *                         a non-NULL C2 is an fp32 [NA] vector that receives += sum_k A[a][k]: with A = dY this is the
+ *                         bias gradient of the same Linear, taken from the operand tiles the kernel stages anyway
  * bias may be NULL.  Requirements: lda, ldb multiples of 8; NA multiple of 4 (epilogues 0-4). */
 int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
                      int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided, int b_kstrided,

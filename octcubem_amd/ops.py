@@ -242,15 +242,18 @@ def _splitk_for(n_out_tiles: int, ktiles: int, target_blocks: int) -> int:
     return max(1, min(s, ktiles // 8 if ktiles >= 8 else 1))
 
 
-def linear_wgrad_accum(dy: torch.Tensor, x: torch.Tensor, gw: torch.Tensor):
-    """gw[N,K] (f32) += dy[M,N].T @ x[M,K]."""
+def linear_wgrad_accum(dy: torch.Tensor, x: torch.Tensor, gw: torch.Tensor, gb: Optional[torch.Tensor] = None):
+    """gw[N,K] (f32) += dy[M,N].T @ x[M,K]; with ``gb`` (f32 [N]) also gb += dy.sum(0) -- the bias gradient, taken from the
+    dY tiles the weight-gradient kernel stages anyway (one extra MFMA per k-step in the first column of tiles) instead of a
+    separate pass over dY."""
     M, N = dy.shape
     K = x.shape[1]
     big = N >= 256 and K >= 256 and not FORCE_SMALL_TILE          # mirrors the tile choice in octmae_gemm_bf16
     t = 256 if big else 128
     tiles = ((N + t - 1) // t) * ((K + t - 1) // t)
     ktiles = (M + 63) // 64
-    _gemm(dy, x, gw, N, K, M, dy.stride(0), x.stride(0), gw.stride(0), 1, 1, EPI_ACCUM, splitk=_splitk_for(tiles, ktiles, 256 if big else 1024))
+    _gemm(dy, x, gw, N, K, M, dy.stride(0), x.stride(0), gw.stride(0), 1, 1, EPI_ACCUM, C2=gb,
+          splitk=_splitk_for(tiles, ktiles, 256 if big else 1024))
 
 
 def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float):
@@ -399,9 +402,7 @@ class LinearFn(torch.autograd.Function):
         N = w_lp.shape[0]
         dyb = _as2d_bf16(dy, N)
         gw, gb = ctx.gw(), ctx.gb()
-        linear_wgrad_accum(dyb, x2, gw)
-        if gb is not None:
-            colsum_accum(dyb, gb)
+        linear_wgrad_accum(dyb, x2, gw, gb)
         notify_grad_ready(ctx.params)
         dx = linear_dgrad(dyb, w_lp).view(ctx.shp) if ctx.needs_input_grad[0] else None
         return (dx, None, None, None, None, None) + (None,) * len(ctx.params)
@@ -423,8 +424,7 @@ class PatchEmbedFn(torch.autograd.Function):
         (patches,) = ctx.saved_tensors
         dyb = _as2d_bf16(dtok, dtok.shape[-1])
         gw = ctx.gw()
-        linear_wgrad_accum(dyb, patches, gw.view(gw.shape[0], -1))
-        colsum_accum(dyb, ctx.gb())
+        linear_wgrad_accum(dyb, patches, gw.view(gw.shape[0], -1), ctx.gb())
         notify_grad_ready(ctx.params)
         return (None,) * 11
 
@@ -466,9 +466,7 @@ class AttentionFn(torch.autograd.Function):
         linear_wgrad_accum(dob, o, gwproj)
         do = linear_dgrad(dob, wproj_lp)
         dqkv = attn_bwd(qkv, o, do, lse, Bn, N, H, HD, scale)
-        if gbqkv is not None:
-            colsum_accum(dqkv, gbqkv)
-        linear_wgrad_accum(dqkv, y2, gwqkv)
+        linear_wgrad_accum(dqkv, y2, gwqkv, gbqkv)
         notify_grad_ready(ctx.params)
         dy = linear_dgrad(dqkv, wqkv_lp).view(ctx.shp)
         dres = dout if has_res else None
@@ -621,9 +619,9 @@ class BlockFn(torch.autograd.Function):
         linear_wgrad_accum(dx2b, o, gwproj)
         do = linear_dgrad(dx2b, wproj)
         dqkv = attn_bwd(qkv, o, do, lse, Bn, N, H, HD, scale)
-        if gbqkv is not None:       # fusing these column sums into the dQ / dK,dV kernels was measured and dropped: the extra
-            colsum_accum(dqkv, gbqkv)    # tail perturbed their register allocation (+10..25 % on the main loops) for a 2 % pass
-        linear_wgrad_accum(dqkv, y1, gwqkv)
+        # the qkv bias gradient rides in the weight-gradient GEMM (column sums of its dY operand); fusing it into the attention
+        # backward kernels had been measured and dropped (+10..25 % on their main loops for a 2 % pass)
+        linear_wgrad_accum(dqkv, y1, gwqkv, gbqkv)
         dy1 = linear_dgrad(dqkv, wqkv)
         # ---- LN1 backward + residual add; its bf16 copy / column sums are what the previous Block's backward needs
         colsum = torch.zeros(C, dtype=F32, device=dx3.device)

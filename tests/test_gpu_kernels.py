@@ -198,6 +198,10 @@ def test_gemm_dgrad_and_wgrad(M, N, K, tile_variant):
     gw2 = gw0.clone()
     ops._gemm(dy, x, gw2, N, K, M, N, K, K, 1, 1, ops.EPI_ACCUM, splitk=1)   # deterministic single-slice path
     assert rel(gw2, gw_ref) < 1e-5
+    gw3, gb3 = gw0.clone(), torch.randn(N, generator=g).to(DEV)        # bias gradient from the dY tiles of the same kernel
+    gb_ref = gb3.double() + dy.double().sum(0)
+    ops.linear_wgrad_accum(dy, x, gw3, gb3)
+    assert rel(gw3, gw_ref) < 1e-5 and rel(gb3, gb_ref) < 2e-5
 
 
 @pytest.mark.parametrize("N,K,M", [(4096, 1024, 1500), (2048, 1280, 900), (1536, 2304, 700), (3072, 1024, 2000)])
