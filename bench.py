@@ -75,8 +75,9 @@ _PMC_KERNEL = {"gemm_wgrad_epi5": ["gemm256p_kernel<true, true, 5, true>", "gemm
                "attn_bwd_fused_hd32": ["attn_bwd_fused_kernel<32>"], "attn_bwd_fused_hd64": ["attn_bwd_fused_kernel<64>"]}
 # A timed kind that is one C-ABI entry point but several launches: the HIP events bracket the whole entry, so `avg_launch_us`
 # is the SUM of these kernels' average durations in a rocprofv3 summary, and `traffic` the sum of their bytes.
-_LAUNCH_GROUP = {"attn_bwd_fused_hd32": ["attn_rowconst_pad_kernel<32>", "attn_bwd_fused_kernel<32>", "attn_bwd_tail_kernel<32>"],
-                 "attn_bwd_fused_hd64": ["attn_rowconst_pad_kernel<64>", "attn_bwd_fused_kernel<64>", "attn_bwd_tail_kernel<64>"]}
+_LAUNCH_GROUP = {"attn_bwd_fused_hd32": ["attn_rowconst_pad_kernel<32>", "attn_bwd_fused_kernel<32>", "attn_bwd_tail1_kernel<32>"],
+                 "attn_bwd_fused_hd64": ["attn_rowconst_pad_kernel<64>", "attn_bwd_fused_kernel<64>", "attn_bwd_tail1_kernel<64>"]}
+# (N = 5121 and 1281 leave ONE key past the last full key block: the single-key tail kernel, attn_bwd_tail1_kernel, runs)
 
 
 def pmc_traffic(kind, micro_batch):
