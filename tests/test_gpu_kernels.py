@@ -314,11 +314,12 @@ def test_attention_fwd_bwd(HD, N, optimistic):
 
 
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("HD,N", [(64, 5121), (32, 5121), (32, 1024), (64, 512), (32, 545), (64, 257)])
+@pytest.mark.parametrize("HD,N", [(64, 5121), (32, 5121), (32, 1024), (64, 512), (32, 545), (64, 257), (32, 513)])
 def test_attention_fwd_bwd_long_sequences(HD, N, fused):
     """Full-length sequences of the decoder (N = 5121, head_dim 32) and of the fine-tune ViT (N = 5121, head_dim 64), plus
-    lengths that are whole key blocks of the fused backward (512 / 256 keys) or leave a multi-group tail, against fp64 on the
-    same bf16-rounded operands; both backward forms."""
+    lengths that are whole key blocks of the fused backward (512 / 256 keys), leave a multi-group tail, or leave exactly ONE key
+    (k * block + 1: the single-key rank-1 tail kernel; N = 1 is in test_attention_fwd_bwd), against fp64 on the same
+    bf16-rounded operands; both backward forms."""
     B, H = 1, 2
     g = torch.Generator().manual_seed(N * 5 + HD)
     qkv = bf(torch.randn(B * N, 3 * H * HD, generator=g)).to(DEV)
@@ -338,7 +339,7 @@ def test_attention_fwd_bwd_long_sequences(HD, N, fused):
 def test_attention_backward_fused_equals_two_kernel_form_closely():
     """Same math, different summation order and one bf16 rounding of dS instead of two: the two forms agree far inside their
     common distance to fp64."""
-    for HD, N, B, H in [(32, 1281, 2, 4), (64, 1281, 2, 4), (32, 197, 3, 2), (64, 50, 2, 2)]:
+    for HD, N, B, H in [(32, 1281, 2, 4), (64, 1281, 2, 4), (32, 197, 3, 2), (64, 50, 2, 2), (32, 300, 1, 24), (64, 257, 2, 20)]:   # H > 16: two passes of the row-constant kernel
         g = torch.Generator().manual_seed(HD + N)
         qkv = bf(torch.randn(B * N, 3 * H * HD, generator=g)).to(DEV)
         do = bf(torch.randn(B * N, H * HD, generator=g)).to(DEV)
