@@ -183,3 +183,27 @@ def test_graft_entry_build_compiles_and_agrees_on_the_abi_number():
     assert int(re.search(r"#define\s+OCTMAE_ABI_VERSION\s+(\d+)", hdr).group(1)) == _lib.load().octmae_abi_version()
     src = open(os.path.join(ROOT, "octcubem_amd", "csrc", "probe.hip")).read()
     assert "return OCTMAE_ABI_VERSION" in src
+
+
+def test_native_comm_bootstrap_over_a_store(monkeypatch):
+    """comm.NativeComm.from_store: rank 0 publishes the 128-byte RCCL unique id under one key of the launcher's store and every
+    rank -- rank 0 included -- constructs its communicator from the bytes it reads back (the communicator itself needs GPUs:
+    its constructor and the id source are replaced; octmae_comm_* argument errors are checked in
+    test_argument_errors_are_reported_without_a_gpu)."""
+    import threading
+    import torch.distributed as dist
+    from octcubem_amd import comm as ocomm
+    made = {}
+    the_id = bytes(range(128))
+    monkeypatch.setattr(ocomm.NativeComm, "unique_id", staticmethod(lambda: the_id))
+    monkeypatch.setattr(ocomm.NativeComm, "__init__", lambda self, idb, rank, world, device: made.__setitem__(rank, (bytes(idb), world, device)))
+    monkeypatch.setattr(ocomm.NativeComm, "__del__", lambda self: None, raising=False)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    store = dist.HashStore()
+    ths = [threading.Thread(target=ocomm.NativeComm.from_store, args=(store, r, 3, r)) for r in (2, 1, 0)]   # rank 0 arrives last
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=30)
+    assert made == {r: (the_id, 3, r) for r in range(3)}
+    assert len(the_id) == ocomm.ID_BYTES == 128
