@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void attn_rowconst_pad_kernel(const bf16_t* __
   // One workgroup per 64 consecutive (padded) query rows of a sample: each wave reduces 16 rows (a row of O / dO is one or two
   // fully coalesced 1 KiB loads), the per-(row, head) results cross LDS and leave as 64 contiguous floats per head -- written
   // straight from the reducing lanes they were 4-byte stores into H different planes (0.46 ms per decoder layer, now 0.25).
-  __shared__ float sh[2][16][64 + 1];           // [lse | delta][head (H <= 16 per pass)][row]
+  __shared__ float sh[16][64 + 1];              // delta: [head (<= 16 per pass)][row]
   const size_t plane = (size_t)B * H * NPAD;
   constexpr int LPH = HD / 8;                   // lanes per head
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void attn_rowconst_pad_kernel(const bf16_t* __
           }
 #pragma unroll
           for (int m = 1; m < LPH; m <<= 1) sum += __shfl_xor(sum, m, 64);
-          if (cok && (lane % LPH) == 0) sh[1][c / LPH - h0][rl] = -sum;
+          if (cok && (lane % LPH) == 0) sh[c / LPH - h0][rl] = -sum;
         }
       }
       __syncthreads();
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void attn_rowconst_pad_kernel(const bf16_t* __
         for (int e = 0; e < 4; ++e) {
           const int q = q0 + r4 + e;
           vl[e] = (q < N) ? -lse[((size_t)b * H + h0 + hh) * N + q] * LOG2E : -1.0e30f;
-          vd[e] = (q < N) ? sh[1][hh][r4 + e] : 0.f;
+          vd[e] = (q < N) ? sh[hh][r4 + e] : 0.f;
         }
         *reinterpret_cast<f32x4*>(rowc + i0) = vl;
         *reinterpret_cast<f32x4*>(rowc + plane + i0) = vd;
