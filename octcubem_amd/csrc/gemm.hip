@@ -897,10 +897,10 @@ static int gemm_impl(const void* A, const void* B, void* C, void* C2, const floa
   // bit 8 of `epilogue` forces the 128-tile kernel, bit 9 the two-stage (un-phased) 256-tile main loop: tests and A/B runs
   // exercise every kernel on the same problem
   const int variant = (epilogue >> 8) & 1;
-  // phased main loop by default whenever an operand is k-strided (dgrad, wgrad: +10..25 %); with two k-contiguous operands
-  // (forward) the plain two-stage loop is as fast at K = 4096 and 12 % faster at K = 1024 (shorter pipeline fill).
-  // bit 9 forces the two-stage loop, bit 10 the phased one.
-  const bool phased = ((epilogue >> 10) & 1) ? true : ((epilogue >> 9) & 1) ? false : (a_kstrided || b_kstrided);
+  // phased main loop by default (dgrad, wgrad: +10..25 % over the two-stage loop; forward, re-measured in round 2 after the
+  // epilogue work: qkv -4 %, proj -11 %, fc2 -8 %, fc1 + GELU -1.5 %, decoder fc1 + GELU +0.6 % -- in round 1 the two-stage loop
+  // had still been 12 % faster at K = 1024).  bit 9 forces the two-stage loop, bit 10 the phased one.
+  const bool phased = ((epilogue >> 10) & 1) ? true : ((epilogue >> 9) & 1) ? false : true;
   epilogue &= 0xff;
   OCTMAE_CHECK_ARG(A && B && C);
   OCTMAE_CHECK_ARG(NA > 0 && NB > 0 && K > 0);
