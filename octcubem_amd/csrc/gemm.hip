@@ -17,8 +17,8 @@
 // t; LDS write of tile t+1 after the MFMAs; one barrier per k-tile), XOR-swizzled LDS images that are
 // conflict-free for ds_read_b128 (k-contiguous) and for the transposed reads (k-strided).
 // That is the SMALL-problem kernel (gemm_kernel).  Problems with at least one full 256-tile each way run the 256 x 256 x 64
-// LDS-DMA kernels further down: gemm256_kernel (two-stage main loop; forward) and gemm256p_kernel (phased main loop with
-// staggered wave groups; dgrad and wgrad).
+// LDS-DMA kernels further down: gemm256p_kernel (phased main loop with staggered wave groups; the default for forward, dgrad and
+// wgrad) and gemm256_kernel (plain two-stage main loop: the round-1 forward kernel, kept selectable for tests and A/B runs).
 #include "common.hpp"
 #include "../../include/octmae.h"
 
