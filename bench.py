@@ -18,6 +18,8 @@ The line also carries
                   bf16 MFMA peak.  `rocprof_kernels` names the kernel(s) one call launches (the fused attention backward is
                   three: row constants, main kernel, tail) -- `avg_launch_us` is the sum of their rocprofv3 averages and
                   `traffic` the sum of their PMC bytes; `executed_tflops` counts the recomputed matmuls as well
+  roofline_hbm -- the same for the dominant BANDWIDTH-bound kernel (LayerNorm backward): algorithmic bytes / measured time vs the
+                  8 TB/s HBM3E peak, `traffic` = its PMC bytes per launch
   cpu_baseline -- the CPU oracle (oracle/mae3d_ref.py, a port of the reference's non-flash model) timed on this host's
                   cores for ONE volume forward+backward (rank 0, N = 1 only)
 """
@@ -72,7 +74,9 @@ _PMC_KERNEL = {"gemm_wgrad_epi5": ["gemm256p_kernel<true, true, 5, true>", "gemm
                "attn_fwd_hd32": ["attn_fwd_kernel<32, true>"], "attn_fwd_hd64": ["attn_fwd_kernel<64, true>"],
                "attn_bwd_dq_hd32": ["attn_bwd_dq_kernel<32>"], "attn_bwd_dq_hd64": ["attn_bwd_dq_kernel<64>"],
                "attn_bwd_dkv_hd32": ["attn_bwd_dkv_kernel<32>"], "attn_bwd_dkv_hd64": ["attn_bwd_dkv_kernel<64>"],
-               "attn_bwd_fused_hd32": ["attn_bwd_fused_kernel<32>"], "attn_bwd_fused_hd64": ["attn_bwd_fused_kernel<64>"]}
+               "attn_bwd_fused_hd32": ["attn_bwd_fused_kernel<32>"], "attn_bwd_fused_hd64": ["attn_bwd_fused_kernel<64>"],
+               "ln_bwd_d1024": ["ln_bwd_kernel<4>"], "ln_bwd_d512": ["ln_bwd_kernel<2>"],
+               "ln_fwd_d1024": ["ln_fwd_kernel<4>"], "ln_fwd_d512": ["ln_fwd_kernel<2>"]}
 # A timed kind that is one C-ABI entry point but several launches: the HIP events bracket the whole entry, so `avg_launch_us`
 # is the SUM of these kernels' average durations in a rocprofv3 summary, and `traffic` the sum of their bytes.
 _LAUNCH_GROUP = {"attn_bwd_fused_hd32": ["attn_rowconst_pad_kernel<32>", "attn_bwd_fused_kernel<32>", "attn_bwd_tail1_kernel<32>"],
@@ -251,6 +255,20 @@ def main():
             "mfu_vs_dense_bf16_peak": vps * 3 * FWD_GFLOP_PER_VOLUME / 1e3 / (PEAK_BF16_TFLOPS * world),
         }
         if kt:
+            hb = {k: v for k, v in kt.items() if k.startswith("ln_")}          # bandwidth-bound kinds (LayerNorm forward / backward)
+            kt = {k: v for k, v in kt.items() if not k.startswith("ln_")}
+            if hb:
+                hdom = max(hb, key=lambda k: hb[k]["total_ms"])
+                h = hb[hdom]
+                gbs = h["bytes"] / (h["total_ms"] * 1e-3) / 1e9
+                htraffic, hsrc, hhead = pmc_traffic(hdom, mb)
+                out["roofline_hbm"] = {"kernel": hdom, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                       "frac": gbs / PEAK_HBM_GBS, "traffic": htraffic, "traffic_source": hsrc, "traffic_head": hhead,
+                                       "avg_launch_us": h["avg_us"], "launches": h["launches"],
+                                       "rocprof_kernels": _PMC_KERNEL.get(hdom, [hdom])[:1],
+                                       "accounting": "algorithmic bytes: dy bf16 + x f32 + residual gradient f32 read, dx f32 + bf16 copy written",
+                                       "all": {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"],
+                                                   "gbs": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1)} for k, v in sorted(hb.items())}}
             tot = sum(v["total_ms"] for v in kt.values())
             dom = max(kt, key=lambda k: kt[k]["total_ms"])
             d = kt[dom]

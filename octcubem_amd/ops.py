@@ -261,8 +261,10 @@ def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float):
     y = torch.empty((M, D), dtype=BF16, device=x.device)
     mean = torch.empty((M,), dtype=F32, device=x.device)
     rstd = torch.empty((M,), dtype=F32, device=x.device)
-    call("octmae_layernorm_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-         M, D, float(eps), _stream())
+    # algorithmic HBM bytes: 4 B read + 2 B written per element (the row statistics are 8 B per row)
+    _launch(f"ln_fwd_d{D}", 0.0, 6.0 * M * D + 8.0 * M,
+            lambda: call("octmae_layernorm_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                         rstd.data_ptr(), M, D, float(eps), _stream()))
     return y, mean, rstd
 
 
@@ -272,8 +274,12 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None, want_bf16=
     dxb = torch.empty((M, D), dtype=BF16, device=x.device) if want_bf16 else None
     from ._lib import load
     ws = torch.empty((load().octmae_layernorm_bwd_ws_floats(M, D),), dtype=F32, device=x.device)
-    call("octmae_layernorm_bwd", dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), _p(dres),
-         dx.data_ptr(), _p(dxb), _p(dgamma), _p(dbeta), _p(dxsum), ws.data_ptr(), M, D, _stream())
+    # algorithmic HBM bytes: dy bf16 + x fp32 read, dx fp32 written, + the incoming residual-stream gradient (fp32) and the bf16
+    # copy of dx when the fused forms are used
+    nbytes = (2.0 + 4.0 + 4.0 + (4.0 if dres is not None else 0.0) + (2.0 if want_bf16 else 0.0)) * M * D + 8.0 * M
+    _launch(f"ln_bwd_d{D}", 0.0, nbytes,
+            lambda: call("octmae_layernorm_bwd", dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), _p(dres),
+                         dx.data_ptr(), _p(dxb), _p(dgamma), _p(dbeta), _p(dxsum), ws.data_ptr(), M, D, _stream()))
     return dx, dxb
 
 
