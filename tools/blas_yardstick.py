@@ -1,3 +1,5 @@
+"""The library GEMM PyTorch dispatches to (hipBLASLt / rocBLAS, plain bf16 output) on the ViT-L shapes: forward, dgrad, wgrad.
+A yardstick for the hand-written kernels (profiles/r02_blas_yardstick.txt), not part of the product path."""
 import torch, time
 def t(f, iters=10):
     for _ in range(3): f()

@@ -1,3 +1,4 @@
+"""fc2 dgrad: plain bf16 epilogue vs x GELU' vs x GELU' + fc1 bias gradient, same process."""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from octcubem_amd import ops

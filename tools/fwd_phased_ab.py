@@ -1,3 +1,4 @@
+"""Forward GEMMs: two-stage vs phased main loop of the 256-tile kernel, same process, interleaved (micro-batch 128 shapes)."""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from octcubem_amd import ops
