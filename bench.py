@@ -7,7 +7,7 @@
 
 A "step" is one optimizer step over the fixed GLOBAL batch (default 256 volumes, BASELINE config 3): every rank runs
 global_batch / N volumes as micro-batches with gradient accumulation (default: 128 volumes on a single GPU -- 246 of its
-268 GiB, with a fall-back to 64 should the warm-up run out of memory -- and min(64, global_batch / N) on N > 1), the
+268 GiB, with a fall-back to 64, agreed across ranks, should a collective-free trial step run out of memory), the
 flat-arena all-reduce overlaps the last micro-batch's backward, then grad-norm + fused AdamW.  Strong scaling: total work per step is fixed.
 Inputs are synthetic fp32 volumes already resident in HBM; weights are the reference's random init; masking noise comes
 from the device RNG inside the timed region.  Rank 0 prints ONE JSON line.
@@ -36,7 +36,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-FWD_GFLOP_PER_VOLUME = 1636.0  # BASELINE.md §3 (algorithmic, multiply-add = 2)
+# BASELINE.md §3 books 1636 GFLOP per forward with the patch embedding over all 5120 tokens (8.05 GF); this build embeds the
+# 1280 KEPT tokens only (2.0 GF, output-identical: SURVEY §8 R1), so the model-FLOP rate counts what is executed: 1636 - 6.05.
+FWD_GFLOP_PER_VOLUME = 1629.95
 
 
 def cpu_baseline(timed_iters=3):
@@ -65,12 +67,13 @@ def cpu_baseline(timed_iters=3):
                       f" s, loss {float(loss):.4f}"}
 
 
-# bench kernel kind -> kernel name(s) in the PMC file (k-strided operands run the phased main loop, gemm256p_kernel)
+# bench kernel kind -> kernel name(s) in the PMC file (every 256-tile GEMM runs the phased main loop, gemm256p_kernel, since
+# 993adab; the two-stage gemm256_kernel names stay listed for PMC files collected before that)
 _PMC_KERNEL = {"gemm_wgrad_epi5": ["gemm256p_kernel<true, true, 5, true>", "gemm256_kernel<true, true, 5, true>"],
                "gemm_dgrad_epi0": ["gemm256p_kernel<true, false, 0, false>", "gemm256_kernel<true, false, 0, false>"],
                "gemm_dgrad_epi4": ["gemm256p_kernel<true, false, 4, false>", "gemm256_kernel<true, false, 4, false>"],
-               "gemm_fwd_epi0": ["gemm256_kernel<false, false, 0, false>"], "gemm_fwd_epi2": ["gemm256_kernel<false, false, 2, false>"],
-               "gemm_fwd_epi3": ["gemm256_kernel<false, false, 3, false>"],
+               "gemm_fwd_epi0": ["gemm256p_kernel<false, false, 0, false>", "gemm256_kernel<false, false, 0, false>"], "gemm_fwd_epi2": ["gemm256p_kernel<false, false, 2, false>", "gemm256_kernel<false, false, 2, false>"],
+               "gemm_fwd_epi3": ["gemm256p_kernel<false, false, 3, false>", "gemm256_kernel<false, false, 3, false>"],
                "attn_fwd_hd32": ["attn_fwd_kernel<32, true>"], "attn_fwd_hd64": ["attn_fwd_kernel<64, true>"],
                "attn_bwd_dq_hd32": ["attn_bwd_dq_kernel<32>"], "attn_bwd_dq_hd64": ["attn_bwd_dq_kernel<64>"],
                "attn_bwd_dkv_hd32": ["attn_bwd_dkv_kernel<32>"], "attn_bwd_dkv_hd64": ["attn_bwd_dkv_kernel<64>"],
@@ -114,10 +117,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--global-batch", type=int, default=256)
     ap.add_argument("--micro-batch", type=int, default=0,
-                    help="volumes per forward/backward; 0 = auto: 128 on a single GPU when it fits (falls back to 64 on an "
-                         "out-of-memory error during warm-up), min(64, global_batch / N) otherwise")
+                    help="volumes per forward/backward; 0 = auto: 128 when the per-rank share is a multiple of it and it fits on "
+                         "every rank (falls back to 64, agreed across ranks), min(64, global_batch / N) otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-per-rank-proxy", action="store_true")
     ap.add_argument("--clip-grad", type=float, default=None)
     ap.add_argument("--force-reducer", action="store_true", help="single rank: still create the RCCL group and run the reducer")
     ap.add_argument("--torch-nccl", action="store_true", help="exchange through torch.distributed's NCCL group instead of octmae_comm_*")
@@ -164,11 +168,14 @@ def main():
 
     assert args.global_batch % world == 0
     per_rank = args.global_batch // world
+    big_ok = per_rank % 128 == 0 and torch.cuda.mem_get_info(dev)[1] >= 280e9
     if args.micro_batch > 0:
         candidates = [min(args.micro_batch, per_rank)]
-    elif world == 1 and per_rank % 128 == 0 and torch.cuda.mem_get_info(dev)[1] >= 280e9:
+    elif big_ok:
         # ~1.9 GiB of saved activations per volume: 128 volumes take 246 of the 268 GiB; +1.6 % over 64 (longer k-loops in the
-        # weight-gradient GEMMs, fewer tile-round tails).  Only without peers: a rank that fell back alone would hang the others.
+        # weight-gradient GEMMs, fewer tile-round tails).  With peers the ranks must AGREE: the trial below runs without any
+        # collective, then one MAX all-reduce of "it did not fit here" decides for everybody (a rank that fell back alone
+        # would leave the others waiting in the gradient exchange).
         candidates = [128, 64]
     else:
         candidates = [min(64, per_rank)]
@@ -191,38 +198,60 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for ci, mb in enumerate(candidates):
-        assert per_rank % mb == 0
-        accum = per_rank // mb
+    def agree_failed(failed: bool) -> bool:
+        if comm is not None:
+            return comm.all_reduce_scalar(1.0 if failed else 0.0, ocomm.MAX) > 0.0
+        if use_dist:
+            t = torch.tensor([1.0 if failed else 0.0], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item()) > 0.0
+        return failed
+
+    def make_step(global_batch, mb):
+        """One optimizer step over `global_batch` volumes (this rank's share as micro-batches of `mb`), on fresh synthetic data."""
+        per = global_batch // world
+        assert per % mb == 0
+        accum_ = per // mb
         g = torch.Generator(device=dev).manual_seed(1234 + rank)   # rank r sees different volumes (seed + rank, main_pretrain…:306)
-        pool = None
+        pool_ = [torch.rand(mb, 1, 60, 256, 256, device=dev, generator=g) for _ in range(min(accum_, 2))]
+
+        def step_(exchange=True):
+            opt.zero_grad()
+            last = None
+            for i in range(accum_):
+                if os.environ.get("OCTMAE_BENCH_FAKE_OOM") and mb == 128:     # exercises the fallback (tests only)
+                    raise torch.OutOfMemoryError("simulated")
+                loss_, _, _ = model(pool_[i % len(pool_)], mask_ratio=0.75)
+                last = loss_
+                scaler(loss_ / accum_, opt, parameters=params, update_grad=(exchange and i == accum_ - 1), clip_grad=args.clip_grad)
+            return last
+        return step_, accum_
+
+    for ci, mb in enumerate(candidates):
+        failed = False
+        step = None
         try:
-            pool = [torch.rand(mb, 1, 60, 256, 256, device=dev, generator=g) for _ in range(min(accum, 2))]
-
-            def step():
-                opt.zero_grad()
-                last = None
-                for i in range(accum):
-                    if os.environ.get("OCTMAE_BENCH_FAKE_OOM") and mb == 128:     # exercises the fallback (tests only)
-                        raise torch.OutOfMemoryError("simulated")
-                    loss, _, _ = model(pool[i % len(pool)], mask_ratio=0.75)
-                    last = loss
-                    scaler(loss / accum, opt, parameters=params, update_grad=(i == accum - 1), clip_grad=args.clip_grad)
-                return last
-
-            for _ in range(max(args.warmup, 1) if len(candidates) > 1 and ci == 0 else args.warmup):
-                step()
-            fence()
-            break
+            step, accum = make_step(args.global_batch, mb)
+            if len(candidates) > 1 and ci == 0:
+                step(exchange=False)            # the trial: every allocation of a step, no collective, no optimizer update
+                torch.cuda.synchronize()
         except torch.OutOfMemoryError:
-            if ci + 1 == len(candidates):
-                raise
-            pool = None
+            failed = True
+        if len(candidates) > 1 and ci == 0 and agree_failed(failed):
+            step = None
             torch.cuda.synchronize()
             import gc
             gc.collect()
             torch.cuda.empty_cache()
-            print(f"[bench] micro-batch {mb} does not fit, falling back to {candidates[ci + 1]}", file=sys.stderr, flush=True)
+            print(f"[bench] rank {rank}: micro-batch {mb} does not fit on every rank, falling back to {candidates[ci + 1]}",
+                  file=sys.stderr, flush=True)
+            continue
+        if failed:
+            raise torch.OutOfMemoryError(f"micro-batch {mb} does not fit")
+        for _ in range(args.warmup):
+            step()
+        fence()
+        break
     if not args.no_kernel_timing:
         ops.KTIMER = ops.KernelTimer()
     t0 = time.perf_counter()
@@ -239,6 +268,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_value = float(loss)
+
+    # One-GPU proxy for strong scaling: what ONE rank of an N-GPU run executes per step -- global batch
+    # 256 / N in one micro-batch -- timed on this GPU with the same model, optimizer and kernels; the ratio of its rate to the
+    # 256-volume rate is the scaling efficiency before any exposed communication.
+    proxy = None
+    if world == 1 and not args.no_per_rank_proxy and args.global_batch == 256:
+        proxy = {}
+        main_rate = args.steps * args.global_batch / dt
+        for n_ranks in (2, 4, 8):
+            gb = args.global_batch // n_ranks
+            pstep, _ = make_step(gb, min(gb, 128))
+            for _ in range(2):
+                pstep()
+            torch.cuda.synchronize()
+            k = 4
+            t1 = time.perf_counter()
+            for _ in range(k):
+                pstep()
+            torch.cuda.synchronize()
+            pdt = (time.perf_counter() - t1) / k
+            proxy[str(n_ranks)] = {"volumes_per_rank": gb, "ms_per_step": 1e3 * pdt, "volumes_per_s_per_gpu": gb / pdt,
+                                   "ratio_to_256": (gb / pdt) / main_rate}
+            del pstep
 
     if rank == 0:
         vps = args.steps * args.global_batch / dt
@@ -294,6 +346,10 @@ def main():
                 xfl = sum(kt[k]["exec_flops"] for k in att)
                 out["attention_qk_pv"] = {"tflops": fl / (ms * 1e-3) / 1e12, "frac_of_bf16_peak": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                                           "executed_tflops": xfl / (ms * 1e-3) / 1e12, "ms": ms}
+        if proxy is not None:
+            out["per_rank_proxy"] = {"what": "one GPU running the per-rank share of an N-GPU step (256 / N volumes, one micro-batch, "
+                                             "no communication): ratio_to_256 = its volumes/s over this line's value",
+                                     "by_n_gpus": proxy}
         if use_dist:
             red = None
             if reducer is not None:

@@ -51,11 +51,18 @@ class NativeComm:
 
     @classmethod
     def from_store(cls, store, rank: int, world: int, device: int, key: str = "octmae/comm_id/0") -> "NativeComm":
-        """Rank 0 creates the RCCL unique id and publishes it under ``key`` of a torch.distributed store; everyone joins."""
+        """Rank 0 creates the RCCL unique id and publishes it under ``key`` of a torch.distributed store; everyone joins.
+        The published key carries a GENERATION: every rank counts itself in with ``store.add(key + "/arrivals", 1)`` and the
+        generation is (arrival - 1) // world -- communicator creation is collective (ncclCommInitRank returns only when all
+        ranks have joined), so the ``world`` arrivals of one creation are complete before the first of the next.  A second
+        communicator on the same store (re-initialisation after destroy(), a library and a benchmark both bootstrapping) can
+        therefore never read the previous, stale id and hang with mismatched ids."""
         torch.cuda.set_device(device)
+        gen = (int(store.add(key + "/arrivals", 1)) - 1) // world
+        skey = f"{key}#{gen}"
         if rank == 0:
-            store.set(key, cls.unique_id())
-        id_bytes = bytes(store.get(key))
+            store.set(skey, cls.unique_id())
+        id_bytes = bytes(store.get(skey))
         return cls(id_bytes, rank, world, device)
 
     @classmethod

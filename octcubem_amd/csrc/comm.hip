@@ -154,7 +154,13 @@ extern "C" int octmae_comm_init(void** comm_out, const void* id_bytes_host, int 
   __builtin_memcpy(&id, id_bytes_host, sizeof(id));
   int rc = 0;
   do {
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    // Highest priority the device offers: the compute kernels of the step hold every CU's LDS for whole tile rounds, and a
+    // default-priority communication stream would see RCCL's workgroups queue behind them; with priority the dispatcher hands
+    // freed CUs to the collective first, so a chunk's exchange starts when it is launched, not when backward thins out.
+    int prio_least = 0, prio_greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (e != hipSuccess) { rc = (int)e; break; }
+    e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest);
     if (e != hipSuccess) { rc = (int)e; break; }
     e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
     if (e != hipSuccess) { rc = (int)e; break; }

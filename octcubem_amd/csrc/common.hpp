@@ -47,25 +47,48 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- GELU (timm Mlp act_layer=nn.GELU, exact-erf form x * Phi(x)) ---------------------------------------------
-// Phi(x) = 0.5 + u * P(u^2), u = clamp(x, +-4.5): odd minimax polynomial of degree 15, |Phi error| <= 7.8e-5 (fp32 Horner),
-// i.e. 50x below the bf16 resolution of the stored activation.  No transcendental: the epilogue of the fc1 GEMM is VALU
+// Phi(x) = 0.5 + u * P(u^2), u = clamp(x, +-4.2): odd minimax polynomial of degree 19, |Phi error| <= 1.4e-5 as evaluated (fp32
+// Horner); the bf16-rounded activation differs from the erf form's by 2-4e-5 relative L2 on N(0, 0.5 .. 4) pre-activations
+// (the degree-15 fit used until round 3, |Phi error| 7.8e-5, cost 7e-4 there: the largest term of the "polynomial vs erf" ledger).  No transcendental: the epilogue of the fc1 GEMM is VALU
 // work that the MFMA pipe cannot hide at one workgroup per CU (the A&S erf form with v_rcp + v_exp cost 2.4x more).
-// The backward uses a separate fit of gelu'(x) = Phi(x) + x phi(x) = 0.5 + u * Q(u^2), u = clamp(x, +-5), |error| <= 4.4e-4.
+// The backward evaluates gelu'(x) = Phi(x) + x phi(x) from the erf form itself (dgelu_f below, |error| <= 3e-7): its epilogue
+// waits for HBM (it streams the saved pre-activation), so two transcendentals per element are hidden there.
 __device__ __forceinline__ float gelu_phi(float x) {
-  const float u = __builtin_amdgcn_fmed3f(x, -4.5f, 4.5f);
+  const float u = __builtin_amdgcn_fmed3f(x, -4.2f, 4.2f);
   const float t = u * u;
-  float p = -7.715688019e-10f;
-  p = fmaf(p, t, 7.192630176e-08f);
-  p = fmaf(p, t, -2.879689972e-06f);
-  p = fmaf(p, t, 6.548595686e-05f);
-  p = fmaf(p, t, -9.478268993e-04f);
-  p = fmaf(p, t, 9.327514321e-03f);
-  p = fmaf(p, t, -6.568239007e-02f);
-  p = fmaf(p, t, 3.986432605e-01f);
+  float p = -2.306640613e-12f;
+  p = fmaf(p, t, 2.495095069e-10f);
+  p = fmaf(p, t, -1.216585654e-08f);
+  p = fmaf(p, t, 3.568801260e-07f);
+  p = fmaf(p, t, -7.116507187e-06f);
+  p = fmaf(p, t, 1.035454878e-04f);
+  p = fmaf(p, t, -1.148414365e-03f);
+  p = fmaf(p, t, 9.898752642e-03f);
+  p = fmaf(p, t, -6.641823237e-02f);
+  p = fmaf(p, t, 3.989180135e-01f);
   return fmaf(u, p, 0.5f);
 }
 __device__ __forceinline__ float gelu_f(float x) { return x * gelu_phi(x); }
-__device__ __forceinline__ float dgelu_f(float x) {
+// gelu'(x) = Phi(x) + x phi(x), nn.GELU's exact (erf) derivative (models_mae_joint_res_flash_attn.py:141 act_layer under
+// autograd).  With a = |x|: Phi(a) = 1 - phi(a) (b1 t + ... + b5 t^5), t = 1 / (1 + p a) (Abramowitz & Stegun 26.2.17,
+// |error| < 7.5e-8), so gelu'(a) = 1 - g with g = phi(a) (poly(t) - a), and gelu'(-a) = g.  1 / sqrt(2 pi) is folded into the
+// coefficients; phi through the hardware exp2.  Measured against float64 over [-12, 12]: |error| <= 3e-7 (tests/test_gpu_kernels.py).
+// (Until round 3 this was an odd degree-19 polynomial, 0.5 + u Q(u^2): its fp32 Horner evaluation cancels, |error| 4.4e-4,
+// which cost up to 3.3e-3 on q / k weight gradients -- kept as dgelu_poly_f for the A/B, build with -DOCTMAE_DGELU_POLY.)
+__device__ __forceinline__ float dgelu_exact_f(float x) {
+  const float a = __builtin_fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.2316419f, a, 1.0f));
+  const float e = __builtin_amdgcn_exp2f(a * a * -0.72134752044448170f);        // exp(-a^2 / 2)
+  float w = 0.53070271f;                                                          // b5 / sqrt(2 pi)
+  w = fmaf(w, t, -0.72657601f);
+  w = fmaf(w, t, 0.71070687f);
+  w = fmaf(w, t, -0.14224837f);
+  w = fmaf(w, t, 0.12741479f);
+  w = w * t;
+  const float g = e * fmaf(-0.39894228040143268f, a, w);
+  return 0.5f + __builtin_copysignf(0.5f - g, x);
+}
+__device__ __forceinline__ float dgelu_poly_f(float x) {
   const float u = __builtin_amdgcn_fmed3f(x, -5.0f, 5.0f);
   const float t = u * u;
   float q = -8.945184002e-12f;
@@ -89,19 +112,21 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 splat2(float c) { return f32x2{c, c}; }
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 gelu_f2(f32x2 x) {
-  const f32x2 u = {__builtin_amdgcn_fmed3f(x[0], -4.5f, 4.5f), __builtin_amdgcn_fmed3f(x[1], -4.5f, 4.5f)};
+  const f32x2 u = {__builtin_amdgcn_fmed3f(x[0], -4.2f, 4.2f), __builtin_amdgcn_fmed3f(x[1], -4.2f, 4.2f)};
   const f32x2 t = u * u;
-  f32x2 p = splat2(-7.715688019e-10f);
-  p = pk_fma(p, t, splat2(7.192630176e-08f));
-  p = pk_fma(p, t, splat2(-2.879689972e-06f));
-  p = pk_fma(p, t, splat2(6.548595686e-05f));
-  p = pk_fma(p, t, splat2(-9.478268993e-04f));
-  p = pk_fma(p, t, splat2(9.327514321e-03f));
-  p = pk_fma(p, t, splat2(-6.568239007e-02f));
-  p = pk_fma(p, t, splat2(3.986432605e-01f));
+  f32x2 p = splat2(-2.306640613e-12f);
+  p = pk_fma(p, t, splat2(2.495095069e-10f));
+  p = pk_fma(p, t, splat2(-1.216585654e-08f));
+  p = pk_fma(p, t, splat2(3.568801260e-07f));
+  p = pk_fma(p, t, splat2(-7.116507187e-06f));
+  p = pk_fma(p, t, splat2(1.035454878e-04f));
+  p = pk_fma(p, t, splat2(-1.148414365e-03f));
+  p = pk_fma(p, t, splat2(9.898752642e-03f));
+  p = pk_fma(p, t, splat2(-6.641823237e-02f));
+  p = pk_fma(p, t, splat2(3.989180135e-01f));
   return x * pk_fma(u, p, splat2(0.5f));
 }
-__device__ __forceinline__ f32x2 dgelu_f2(f32x2 x) {
+__device__ __forceinline__ f32x2 dgelu_poly_f2(f32x2 x) {
   const f32x2 u = {__builtin_amdgcn_fmed3f(x[0], -5.0f, 5.0f), __builtin_amdgcn_fmed3f(x[1], -5.0f, 5.0f)};
   const f32x2 t = u * u;
   f32x2 q = splat2(-8.945184002e-12f);
@@ -116,6 +141,29 @@ __device__ __forceinline__ f32x2 dgelu_f2(f32x2 x) {
   q = pk_fma(q, t, splat2(7.970332990e-01f));
   return pk_fma(u, q, splat2(0.5f));
 }
+__device__ __forceinline__ f32x2 dgelu_exact_f2(f32x2 x) {
+  const f32x2 a = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
+  const f32x2 d = pk_fma(splat2(0.2316419f), a, splat2(1.0f));
+  const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  const f32x2 m = a * a * splat2(-0.72134752044448170f);
+  const f32x2 e = {__builtin_amdgcn_exp2f(m[0]), __builtin_amdgcn_exp2f(m[1])};
+  f32x2 w = splat2(0.53070271f);
+  w = pk_fma(w, t, splat2(-0.72657601f));
+  w = pk_fma(w, t, splat2(0.71070687f));
+  w = pk_fma(w, t, splat2(-0.14224837f));
+  w = pk_fma(w, t, splat2(0.12741479f));
+  w = w * t;
+  const f32x2 g = e * pk_fma(splat2(-0.39894228040143268f), a, w);
+  const f32x2 hmg = splat2(0.5f) - g;
+  return f32x2{0.5f + __builtin_copysignf(hmg[0], x[0]), 0.5f + __builtin_copysignf(hmg[1], x[1])};
+}
+#ifdef OCTMAE_DGELU_POLY
+__device__ __forceinline__ float dgelu_f(float x) { return dgelu_poly_f(x); }
+__device__ __forceinline__ f32x2 dgelu_f2(f32x2 x) { return dgelu_poly_f2(x); }
+#else
+__device__ __forceinline__ float dgelu_f(float x) { return dgelu_exact_f(x); }
+__device__ __forceinline__ f32x2 dgelu_f2(f32x2 x) { return dgelu_exact_f2(x); }
+#endif
 
 // ---- MFMA wrappers ---------------------------------------------------------------------------
 // D(32x32) += A(32x16) * B(16x32).  lane l: r = l & 31, h = l >> 5.

@@ -44,17 +44,32 @@ def _chk(t: torch.Tensor, dtype, name: str):
 # ------------------------------------------------------------------------------------------------
 # grad-ready notification (used by parallel.FlatGradReducer)
 # ------------------------------------------------------------------------------------------------
-_grad_ready_cb: Optional[Callable[[Sequence[torch.nn.Parameter]], None]] = None
+# Several reducers may listen during one backward (the COEM step drives one FlatGradReducer per tower): every subscriber sees
+# every notification and picks out the parameters of its own arena.  Keyed by owner so that a reducer replaces / removes only
+# its own entry (a single global callback let the second reducer's begin_backward() silence the first).
+_grad_ready_subs: dict = {}
+
+
+def add_grad_ready_callback(owner, cb: Callable[[Sequence[torch.nn.Parameter]], None]):
+    _grad_ready_subs[id(owner)] = cb
+
+
+def remove_grad_ready_callback(owner):
+    _grad_ready_subs.pop(id(owner), None)
 
 
 def set_grad_ready_callback(cb):
-    global _grad_ready_cb
-    _grad_ready_cb = cb
+    """Single-subscriber form kept for callers that own the whole backward: replaces every subscription (None: clears)."""
+    _grad_ready_subs.clear()
+    if cb is not None:
+        _grad_ready_subs[0] = cb
 
 
 def notify_grad_ready(params):
-    if _grad_ready_cb is not None:
-        _grad_ready_cb([p for p in params if p is not None])
+    if _grad_ready_subs:
+        ps = [p for p in params if p is not None]
+        for cb in list(_grad_ready_subs.values()):
+            cb(ps)
 
 
 def grad_buf(p: torch.nn.Parameter) -> torch.Tensor:

@@ -128,7 +128,7 @@ class FlatGradReducer:
         self._in_backward = True
         self._reports = {}
         self._overlap_now = self._sync and self.overlap and not (self.multi_use and self._expected is None)
-        ops.set_grad_ready_callback(self._on_ready if self._overlap_now else self._on_ready_note)
+        ops.add_grad_ready_callback(self, self._on_ready if self._overlap_now else self._on_ready_note)
         if self._overlap_now and self._frozen:
             # chunks made only of parameters that never report (zeros in the arena) are exchanged NOW, under the whole backward
             for c in range(len(self.bounds)):
@@ -202,9 +202,13 @@ class FlatGradReducer:
     def finish(self):
         """Call after backward, before the optimizer: launches whatever has not been exchanged yet (parameters that
         received no gradient this step) and makes the compute stream wait for the communication stream."""
-        ops.set_grad_ready_callback(None)
+        ops.remove_grad_ready_callback(self)
         self._in_backward = False
+        # outside a begin_backward() / finish() window the autograd hooks only note (an evaluation or reference backward must
+        # neither launch collectives nor trip the multi-use count of the step that has just ended)
+        self._overlap_now = False
         if not self._sync:
+            self._reports = {}
             return
         for c in range(len(self.bounds)):
             self._launch(c)
@@ -217,6 +221,7 @@ class FlatGradReducer:
         self._pending = []
         if self.multi_use and self._expected is None:
             self._expected = dict(self._reports)
+        self._reports = {}
         # learning step: whoever reported on no rank is "cold"; agreed across ranks once, then frozen
         if self.overlap and not self._frozen:
             self._cold = self._agree_cold()

@@ -11,8 +11,10 @@ rounding inserted at exactly the points where the HIP path (octcubem_amd.ops.Blo
             LayerNorm backward, residual adds, bias / weight gradients in fp32.
   weights   the MFMA operands are the bf16 mirror of the fp32 master weights.
 
-GELU and GELU' are the epilogues' polynomials (exact_gelu=False; their fits are bounded at 7.8e-5 / 4.4e-4 absolute, and the
-test prices what they cost against the erf forms).  What remains between this model and the HIP result is accumulation order
+GELU is the fc1 epilogue's polynomial (exact_gelu=False; |Phi error| <= 1.4e-5 absolute, far below the bf16 resolution of the stored
+activation; the test prices what it costs against the erf form).  GELU' is the erf form itself: since round 3 the fc2-dgrad
+epilogue evaluates it to 3e-7 (csrc/common.hpp dgelu_exact_f; the degree-19 polynomial it replaced, |error| 4.4e-4, is kept
+here as dgelu_poly only to show what it used to cost).  What remains between this model and the HIP result is accumulation order
 (fp32 vs float64), the hardware exp2, and rare rounding flips of values that land within 1e-7 of a bf16 tie.  The GPU test
 (tests/test_gpu_rounding_model.py) requires <= 1e-3 relative for every output, which separates "bf16 operand rounding" from
 "kernel arithmetic error": the plain fp32 oracle differs from both by the 2^-9-per-operation rounding the north star's 1e-3
@@ -57,18 +59,19 @@ def dgelu(x):
 
 
 def gelu_poly(x):
-    """The GEMM epilogue's GELU (csrc/common.hpp gelu_f): x * (0.5 + u P(u^2)), u = clamp(x, +-4.5), |Phi error| <= 7.8e-5."""
-    u = x.clamp(-4.5, 4.5)
+    """The GEMM epilogue's GELU (csrc/common.hpp gelu_f): x * (0.5 + u P(u^2)), u = clamp(x, +-4.2), |Phi error| <= 1.4e-5."""
+    u = x.clamp(-4.2, 4.2)
     t = u * u
-    p = torch.full_like(x, -7.715688019e-10)
-    for c in (7.192630176e-08, -2.879689972e-06, 6.548595686e-05, -9.478268993e-04, 9.327514321e-03, -6.568239007e-02,
-              3.986432605e-01):
+    p = torch.full_like(x, -2.306640613e-12)
+    for c in (2.495095069e-10, -1.216585654e-08, 3.568801260e-07, -7.116507187e-06, 1.035454878e-04, -1.148414365e-03,
+              9.898752642e-03, -6.641823237e-02, 3.989180135e-01):
         p = p * t + c
     return x * (u * p + 0.5)
 
 
 def dgelu_poly(x):
-    """The fc2-dgrad epilogue's GELU' (csrc/common.hpp dgelu_f): 0.5 + u Q(u^2), u = clamp(x, +-5), |error| <= 4.4e-4."""
+    """The fc2-dgrad epilogue's GELU' UNTIL round 3 (csrc/common.hpp dgelu_poly_f): 0.5 + u Q(u^2), u = clamp(x, +-5),
+    |error| <= 4.4e-4.  Not used by the model below any more (poly_dgelu=True brings it back for comparisons)."""
     u = x.clamp(-5.0, 5.0)
     t = u * u
     q = torch.full_like(x, -8.945184002e-12)
@@ -79,7 +82,7 @@ def dgelu_poly(x):
 
 
 def block_forward_backward(P: Dict[str, torch.Tensor], x: torch.Tensor, dx3: torch.Tensor, num_heads: int, eps: float = 1e-6,
-                           fused_bwd: bool = True, exact_gelu: bool = False):
+                           fused_bwd: bool = True, exact_gelu: bool = False, poly_dgelu: bool = False):
     """P: the Block's parameters by their reference names (norm1.weight, attn.q.weight, ..., mlp.fc2.bias), fp32.
     x, dx3: [B, N, C] fp32.  Returns (x3, dx, grads) in float64."""
     B, N, C = x.shape
@@ -119,7 +122,7 @@ def block_forward_backward(P: Dict[str, torch.Tensor], x: torch.Tensor, dx3: tor
     d3b = bf(dx3)
     G["mlp.fc2.weight"] = (d3b.reshape(-1, C).T @ act.reshape(-1, act.shape[-1]))
     G["mlp.fc2.bias"] = dx3.reshape(-1, C).sum(0)
-    dpre = bf(bf(d3b @ w2) * (dgelu(pre) if exact_gelu else dgelu_poly(pre)))
+    dpre = bf(bf(d3b @ w2) * (dgelu_poly(pre) if poly_dgelu else dgelu(pre)))
     G["mlp.fc1.bias"] = dpre.reshape(-1, dpre.shape[-1]).sum(0)
     G["mlp.fc1.weight"] = dpre.reshape(-1, dpre.shape[-1]).T @ y2.reshape(-1, C)
     dy2 = bf(dpre @ w1)

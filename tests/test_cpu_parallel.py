@@ -131,3 +131,65 @@ def test_flat_grad_reducer_gloo_world2():
     for i, (off, n) in enumerate(a["offsets"]):
         exp = torch.full((n,), 1.5) if i < 3 else torch.zeros(n)
         assert torch.allclose(a["grad_hook"][off:off + n], exp), i
+
+
+def _worker_two_reducers(rank, world, port, q):
+    """Two reducers (one per tower, as coem.train_step drives them) listening during ONE backward, over three steps: the second
+    subscription must not silence the first (with a single global callback tower A's parameters never reported, were
+    all marked cold in the learning step and were exchanged at begin_backward() -- before backward wrote them -- ever after)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from octcubem_amd import ops
+    from octcubem_amd.parallel import FlatGradReducer
+    shapes_a = [(33, 10), (100,), (64, 8), (50,)]
+    shapes_b = [(20, 20), (300,), (16,)]
+    A, B = FakeArena(shapes_a, seed=1), FakeArena(shapes_b, seed=2)
+    reds = [FlatGradReducer(FakeModel(A), n_chunks=2), FlatGradReducer(FakeModel(B), n_chunks=2)]
+    res = {"rank": rank, "ok": True, "why": ""}
+    for step in range(3):
+        A.grad.zero_(); B.grad.zero_()
+        b0 = [r.stats["launched_in_backward"] for r in reds]
+        for r in reds:
+            r.begin_backward(sync=True)
+        # backward order: tower B's parameters first, then tower A's (interleaved notifications through ONE notify entry point)
+        val = float((rank + 1) * (step + 1))
+        for p in list(reversed(B.params)) + list(reversed(A.params)):
+            p.grad.add_(val); ops.notify_grad_ready([p])
+        for r in reds:
+            r.finish()
+        exp = 1.5 * (step + 1)
+        for name, ar, shapes in (("A", A, shapes_a), ("B", B, shapes_b)):
+            for (nm, p, off, n) in ar.entries:
+                if not torch.allclose(ar.grad[off:off + n], torch.full((n,), exp)):
+                    res["ok"] = False; res["why"] += f" step{step}:{name}.{nm}"
+        for i, r in enumerate(reds):
+            if r._cold:
+                res["ok"] = False; res["why"] += f" step{step}:reducer{i} has cold parameters {len(r._cold)}"
+            if step > 0 and r.stats["launched_in_backward"] - b0[i] != len(r.bounds):
+                res["ok"] = False; res["why"] += f" step{step}:reducer{i} launched {r.stats['launched_in_backward'] - b0[i]} of {len(r.bounds)} in backward"
+    # a backward outside a begin/finish window (evaluation, reference gradient) must not launch or raise
+    before = [r.stats["bytes_total"] for r in reds]
+    loss = sum((p * 2).sum() for p in A.params[:2])
+    loss.backward()
+    ops.notify_grad_ready([A.params[0]])
+    if [r.stats["bytes_total"] for r in reds] != before:
+        res["ok"] = False; res["why"] += " exchange outside a window"
+    q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_reducers_share_one_backward_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_two_reducers, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=100) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for o in outs:
+        assert o["ok"], o["why"]

@@ -151,5 +151,20 @@ def test_coem_step_with_reducers_exchanges_both_towers():
             assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7
         assert torch.equal(model.logit_scale.grad, gl)
         assert reds[0].stats["bytes_total"] == 4 * m3.arena.total and reds[1].stats["bytes_total"] == 4 * m2.arena.total
+        # steps AFTER the learning step -- both reducers listen to the same backward; each tower's hot chunks must
+        # go out during backward (after their gradients were written), nothing of a used tower may be "cold", and the result
+        # must still equal the local gradient
+        for step in range(2):
+            b0 = [r.stats["launched_in_backward"] for r in reds]
+            l2 = coem.train_step(model, coem.ClipLoss(), vol, ir, opts, reducers=reds)
+            torch.cuda.synchronize()
+            assert abs(float(l2) - float(l0)) <= 1e-6 * abs(float(l0))
+            for a, b in ((m3.arena.grad, g3), (m2.arena.grad, g2)):
+                assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7
+            for r, mod in zip(reds, (m3, m2)):
+                used = {id(p) for p in mod.parameters() if p.grad is not None and float(p.grad.abs().max()) > 0}
+                assert not (used & set(r._cold)), "a parameter with a gradient was classified cold"
+                hot = sum(1 for c in range(len(r.bounds)) if not r.cold_chunk[c])
+                assert hot >= 1 and r.stats["launched_in_backward"] - b0[reds.index(r)] == len(r.bounds)
     finally:
         comm1.destroy()

@@ -19,6 +19,8 @@ from oracle import bf16_points as R
 from oracle import mae3d_ref as O
 
 DEV = "cuda"
+# polynomial GELU (forward only) vs erf on the float64 model: 4.2e-5 worst (mlp.fc2.weight), it was 3.3e-3 with the polynomial GELU'
+POLY_GELU_BOUND = 1e-4
 
 
 def rel(a, b):
@@ -79,12 +81,13 @@ def test_block_matches_the_rounding_point_model_to_1e_3(C, H, N, B):
         # B*N rows of bf16-rounded dy, where a handful of tie flips show) get 2e-3
         bad = {k: v for k, v in errs.items() if v > (2e-3 if "norm" in k else 1e-3)}
         assert not bad, bad
-        # what the epilogues' polynomial GELU / GELU' (|fit error| <= 7.8e-5 / 4.4e-4) cost against the erf forms, same roundings
+        # what the fc1 epilogue's polynomial GELU (|Phi error| <= 1.4e-5) costs against the erf form, same roundings (GELU' IS the
+        # erf form since round 3: the 3.3e-3 its polynomial used to cost on the q / k weight gradients is gone)
         poly = {"x3": rel(x3_r, x3_e), "dx": rel(dx_r, dx_e)}
         poly.update({"g:" + k: rel(G[k], Ge[k]) for k in G if k != "attn.k.bias"})
         wp = max(poly, key=poly.get)
         print(f"[polynomial GELU vs erf] x3 {poly['x3']:.2e}, dx {poly['dx']:.2e}, largest {wp} {poly[wp]:.2e}")
-        assert max(poly.values()) <= 6e-3
+        assert max(poly.values()) <= POLY_GELU_BOUND, poly
     # the plain fp32 oracle (no rounding anywhere) on the same inputs: the distance the tests in test_gpu_model.py tolerate
     Pr = {f"blocks.0.{k}": v.clone().requires_grad_(True) for k, v in P.items()}
     xr = x.clone().requires_grad_(True)
