@@ -22,9 +22,15 @@ extern "C" {
 
 /* The ONE place the ABI number lives: octmae_abi_version() returns it (csrc/probe.hip), octcubem_amd/_lib.py parses it
  * from this header and refuses a library that reports another number, __graft_entry__.build() and the tests compare the two.
- * 4: octmae_attn_bwd_dq_rowconst.  5: octmae_comm_* (RCCL), octmae_attn_bwd_fused + workspace query. */
-#define OCTMAE_ABI_VERSION 6
+ * 4: octmae_attn_bwd_dq_rowconst.  5: octmae_comm_* (RCCL), octmae_attn_bwd_fused + workspace query.  7: octmae_set_option. */
+#define OCTMAE_ABI_VERSION 7
 int octmae_abi_version(void);
+
+/* Kernel-selection switches for same-process A/B measurements and for tests that cover both forms of a kernel (no reference
+ * counterpart: the reference's kernels come from its libraries).  Returns the previous value, -1 for an unknown key.
+ *   "attn_bwd_hd32_form"   1 (default): one wave per SIMD, 4 x 128 keys per workgroup (csrc/attn_bwd1w.hip)
+ *                          0: two waves per SIMD, 8 x 64 keys (csrc/attn_bwd.hip) -- the round-2 kernel */
+int octmae_set_option(const char* key, int value);
 
 /* ---- GEMM with fused epilogues ------------------------------------------------------------------
  * X[a][b] = sum_k A[a][k] * B[b][k],  A has NA rows, B has NB rows, reduction length K.

@@ -872,11 +872,18 @@ __global__ __launch_bounds__(256) void attn_bwd_tail1_kernel(const bf16_t* __res
   }
 }
 
+// one wave per SIMD, head_dim 32 (attn_bwd1w.hip)
+int launch_attn_bwd_fused1w(const bf16_t* qkv, const bf16_t* dout, const float* rowc, float* dq_ws, bf16_t* dqkv, int B, int N, int NPAD,
+                            int H, int nkb, float scale, hipStream_t st);
+std::atomic<int> g_attn_bwd_hd32_form{1};
+
 template <int HD>
 static int run_fused(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, const float* lse, float* ws, bf16_t* dqkv, int B, int N,
                      int H, float scale, hipStream_t st) {
   using C = BwdCfg<HD>;
-  const int NPAD = (N + 63) / 64 * 64;
+  // one all-padding tile of row constants behind the last query tile: (-1e30, 0), i.e. P = 0 -- the one-wave-per-SIMD kernel
+  // drains its software pipeline on it
+  const int NPAD = (N + 63) / 64 * 64 + 64;
   float* dq_ws = ws;
   float* rowc = ws + (size_t)B * H * N * HD;
   {
@@ -886,7 +893,9 @@ static int run_fused(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, con
     OCTMAE_LAUNCH_CHECK();
   }
   const int nkb = N / C::KB;
-  if (nkb > 0) {
+  if (nkb > 0 && HD == 32 && g_attn_bwd_hd32_form.load(std::memory_order_relaxed) == 1) {
+    if (int rc = launch_attn_bwd_fused1w(qkv, dout, rowc, dq_ws, dqkv, B, N, NPAD, H, nkb, scale, st)) return rc;
+  } else if (nkb > 0) {
     static DynLdsOnce once;
     if (int rc = once.ensure(reinterpret_cast<const void*>(attn_bwd_fused_kernel<HD>), C::LDS)) return rc;
     hipLaunchKernelGGL(attn_bwd_fused_kernel<HD>, dim3(B * H), dim3(512), C::LDS, st, qkv, dout, rowc, dq_ws, dqkv, N, NPAD, H, nkb, scale);
@@ -917,9 +926,15 @@ extern "C" int octmae_debug_bwd_stamps(void* host, int nbytes) {
 }
 #endif
 
+extern "C" int octmae_set_option(const char* key, int value) {
+  if (key == nullptr) return -1;
+  if (__builtin_strcmp(key, "attn_bwd_hd32_form") == 0) return g_attn_bwd_hd32_form.exchange(value ? 1 : 0);
+  return -1;
+}
+
 extern "C" int octmae_attn_bwd_fused_ws_kib(int B, int N, int H, int HD) {
   if (B <= 0 || N <= 0 || H <= 0 || (HD != 32 && HD != 64)) return -1;
-  const size_t npad = (size_t)(N + 63) / 64 * 64;
+  const size_t npad = (size_t)(N + 63) / 64 * 64 + 64;
   const size_t bytes = ((size_t)B * H * N * HD + 2 * (size_t)B * H * npad) * 4;
   const size_t kib = (bytes + 1023) / 1024;
   return kib > 0x7fffffffull ? -2 : (int)kib;

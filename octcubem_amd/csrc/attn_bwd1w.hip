@@ -1,0 +1,310 @@
+// Fused (single-pass) attention backward, head_dim 32, ONE WAVE PER SIMD: the main kernel of octmae_attn_bwd_fused at head_dim 32
+// (decoder: 16 heads x 32, N = 5121).  Same algorithm, inputs, outputs and rounding points as attn_bwd.hip's
+// attn_bwd_fused_kernel<32> (5 matrix products and 1 exp per score, no atomics, bit-reproducible), re-structured for the issue
+// port: that kernel ran two waves per SIMD with two workgroup barriers per 64-query tile and spent ~880-1050 cycles per 32 x 32
+// score block against ~400 of instruction issue; here
+//   * a workgroup is 4 waves with 512 registers each (one per SIMD); a wave owns 128 keys of the 512-key block: dK^T / dV^T of
+//     those keys (128 accumulator registers), their pre-scaled K and V fragments (64) and their K^T fragments (32) stay in
+//     registers for the whole sweep over the queries;
+//   * per 32-query sub-tile a wave does S, dP, exp2, dS, dV^T, dK^T for its four 32-key groups AND the dQ^T product over its
+//     OWN 128 keys: its dS goes through a wave-private LDS image (no barrier: a wave's LDS operations execute in order) and
+//     comes back through transposed reads as the B operand of 8 more 32x32x16 MFMAs;
+//   * the four waves' dQ^T partial tiles (fp32, 4 KB each) are summed through LDS in a fixed order -- wave w sums register quad
+//     w of all four, adds the workspace value of the previous key blocks (brought in by LDS-DMA a tile ahead) and stores -- one
+//     tile LATER, behind the single workgroup barrier of the tile, so no wave ever waits for another's arithmetic;
+//   * Q / dO / row-constant tiles arrive by LDS-DMA through a 3-deep ring two tiles ahead, retired by counted vmcnt.
+// Reference op: backward of softmax((q k^T) scale) v, Pre-training/custom_util/video_vit.py:130-134 under autograd.
+#include "attn_tile.hpp"
+#include "../../include/octmae.h"
+
+namespace octmae {
+
+namespace bwd1w {
+
+constexpr int HD = 32, NW = 4, KW = 128, NG = 4, KB = NW * KW;
+constexpr int LA = 3;                                   // tiles requested ahead of the one being computed
+constexpr int NB = LA + 1;                              // Q / dO / constants ring depth
+constexpr int NOLD = 3;                                 // workspace-value buffers: requested one tile before their tile, read one after
+using T = Tile<HD>;                                     // 64 rows x 64 B, XOR-swizzled 16-byte chunks
+constexpr int QR = 0;                                   // Q ring      [NB][4096]
+constexpr int OR_ = QR + NB * T::BYTES;                 // dO ring     [NB][4096]
+constexpr int CR = OR_ + NB * T::BYTES;                 // constants   [NB][2][64] f32
+constexpr int IMG = CR + NB * 512;                      // per wave: dS image [128 keys][32 queries] bf16 (64-byte rows)
+constexpr int IMG_W = KW * 64;
+constexpr int PART = IMG + NW * IMG_W;                  // dQ^T partial tiles [2 sub-steps][NW][4 quads][64 lanes] f32x4
+constexpr int PART_W = 4096;
+constexpr int OLD = PART + 2 * NW * PART_W;             // workspace values   [NOLD tiles][2 sub-tiles][NW][64 lanes] f32x4
+constexpr int LDS = OLD + NOLD * 2 * NW * 1024;
+constexpr int STG = PART;                               // K rows of the block [512][64 B], staged once per block for the K^T reads
+static_assert(KB * 64 <= 2 * NW * PART_W, "K staging must fit the partial-tile region");
+static_assert(LDS <= 160 * 1024, "LDS budget");
+static_assert((CR % 128) == 0 && (IMG % 128) == 0 && (PART % 128) == 0 && (OLD % 128) == 0, "XOR chunk selectors act on address bits 0..6");
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+template <int CNT>
+__device__ __forceinline__ void wait_vm() {
+  static_assert(CNT >= 0 && CNT < 64, "vmcnt is 6 bits");
+  __builtin_amdgcn_s_waitcnt((CNT & 15) | ((CNT >> 4) << 14) | (7 << 4) | (15 << 8));
+}
+__device__ __forceinline__ void lds_dma16(unsigned m0v, unsigned voff, i32x4_t rsrc) {
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+__device__ __forceinline__ void lds_dma4(unsigned m0v, unsigned voff, i32x4_t rsrc) {
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+__device__ __forceinline__ i32x4_t make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  i32x4_t r = {(int)(unsigned)a, (int)(unsigned)(a >> 32), (int)bytes, 0x00020000};
+  r[0] = __builtin_amdgcn_readfirstlane(r[0]);
+  r[1] = __builtin_amdgcn_readfirstlane(r[1]);
+  r[2] = __builtin_amdgcn_readfirstlane(r[2]);
+  r[3] = __builtin_amdgcn_readfirstlane(r[3]);
+  return r;
+}
+// 8-byte chunk c8 (4 bf16) of row `row` of a [rows][64 B] image: ds_write_b64 by 16 consecutive rows and the transposed reads of
+// 4 consecutive rows (one aligned 256-byte line) are both conflict-free for any within-row permutation that separates the 8
+// even (odd) rows of a 16-row run
+__device__ __forceinline__ int img_off(int row, int c8) { return row * 64 + ((c8 ^ ((row >> 1) & 7)) << 3); }
+
+// dV^T / dK^T accumulate in the ACCUMULATOR half of the register file (128 of this wave's 512 registers), where only MFMAs touch
+// them; the MFMAs whose results the vector ALU consumes (S, dP, dQ^T) are the compiler's builtins with VGPR destinations
+// (-mllvm -amdgpu-mfma-vgpr-form, see the Makefile).  One function cannot have both forms from builtins, hence the asm.  Hazards
+// (the compiler pads nothing inside asm): the A / B operands are written by v_cvt_pk at least two instructions earlier (the
+// generator pins their last producer), the accumulate chain needs no wait states, and the read-out after the loop sits behind
+// explicit s_nops.
+#define MFMA_ACC(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+#ifdef ABL_NO_BARRIER
+#define SUBSTEP_END() __builtin_amdgcn_s_waitcnt(0xC07F)
+#else
+#define SUBSTEP_END()                        \
+  do {                                       \
+    __builtin_amdgcn_s_waitcnt(0xC07F);      \
+    __builtin_amdgcn_s_barrier();            \
+  } while (0)
+#endif
+
+}  // namespace bwd1w
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                                  const float* __restrict__ rowc, float* __restrict__ dq_ws,
+                                                                  bf16_t* __restrict__ dqkv, int N, int NPAD, int H, int nkb,
+                                                                  float scale) {
+  using namespace bwd1w;
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int bh = xcd_remap((int)blockIdx.x, (int)gridDim.x);      // an XCD gets whole samples: their Q / dO rows share lines
+  const int b = bh / H, head = bh % H;
+  const size_t rs = (size_t)3 * H * HD, os = (size_t)H * HD;
+  const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)head * HD;
+  const bf16_t* kb_ = qb + (size_t)H * HD;
+  const bf16_t* vb_ = qb + (size_t)2 * H * HD;
+  const bf16_t* dob = dout + (size_t)b * N * os + (size_t)head * HD;
+  const float sc2 = scale * LOG2E;
+  const int ntiles = (N + 63) / 64;               // NPAD = 64 (ntiles + 1): one all-padding tile of row constants behind the last
+
+  // ---- LDS-DMA plan: a tile is 4 Q pieces + 4 dO pieces of 1 KiB; waves 0, 1 bring Q, waves 2, 3 dO (2 pieces each) and every
+  // wave one row of constants (-lse*log2e: even waves, -delta: odd)
+  const bool isq = wid < 2;                                       // wave-uniform
+  const i32x4_t rsD = isq ? make_rsrc(qb, (unsigned)(((size_t)(N - 1) * rs + HD) * 2)) : make_rsrc(dob, (unsigned)(((size_t)(N - 1) * os + HD) * 2));
+  unsigned dvoff[2], dlds[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int piece = (wid & 1) * 2 + i;
+    const int q = piece * 64 + lane;
+    const int row = q / T::CHUNKS, c = (q % T::CHUNKS) ^ T::sw(row);
+    dvoff[i] = (unsigned)(((size_t)row * (isq ? rs : os) + c * 8) * 2);
+    dlds[i] = (unsigned)((isq ? QR : OR_) + piece * 1024);
+  }
+  const unsigned dstride = (unsigned)(64 * (isq ? rs : os) * 2);
+  const i32x4_t rsC = make_rsrc(rowc + (size_t)(wid & 1) * gridDim.x * NPAD + (size_t)bh * NPAD, (unsigned)((size_t)NPAD * 4));
+  // Q / dO of tile `dt` and the constants of tile `ct` -> ring slot   (3 operations)
+  auto issue = [&](int dt, int ct, int slot) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + dlds[i] + (unsigned)(slot * T::BYTES)));
+      lds_dma16(m0v, dvoff[i] + (unsigned)dt * dstride, rsD);
+    }
+    const unsigned m0c = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + CR + slot * 512 + (wid & 1) * 256));
+    lds_dma4(m0c, (unsigned)((ct * 64 + lane) * 4), rsC);
+  };
+
+  // ---- dQ workspace of this (batch, head): fp32 [N][32]; rows >= N fall outside the descriptor (loads 0, stores dropped).
+  // Wave w owns register quad w of every dQ^T tile: head dims 8 w + 4 h .. + 3 of query r of the sub-tile.
+  float* wsb = dq_ws + (size_t)bh * N * HD;
+  const i32x4_t rsW = make_rsrc(wsb, (unsigned)((size_t)N * HD * 4));
+  const __amdgpu_buffer_rsrc_t rsWs = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(((unsigned long long)(unsigned)rsW[1] << 32) | (unsigned)rsW[0]), 0, rsW[2], 0x00020000);
+  const unsigned wsoff = (unsigned)((r * HD + 8 * wid + 4 * h) * 4);
+  constexpr unsigned WS_SUB = 32 * HD * 4, WS_TILE = 64 * HD * 4, DROP = 0x80000000u;   // DROP: an offset outside every descriptor
+  // workspace values of this wave's quads of `tile` -> OLD buffer   (2 operations; `base` = DROP in the first key block: zeros)
+  auto oldreq = [&](int tile, int buf, unsigned base) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const unsigned m0o = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + OLD + ((buf * 2 + u) * NW + wid) * 1024));
+      lds_dma16(m0o, wsoff + base + (unsigned)tile * WS_TILE + (unsigned)u * WS_SUB, rsW);
+    }
+  };
+
+  // ---- per-lane LDS address parts, fixed for the whole kernel (opaque: not re-derived from the lane id inside the loops)
+  const int tq_ = (lane >> 2) & 3, tp_ = lane & 3, tgi = (lane >> 4) & 1;
+  const unsigned a_const = opaque(lds0 + (unsigned)(CR + 16 * h));
+  const unsigned a_row = opaque(lds0 + (unsigned)(QR + T::off(r, h)));
+  const unsigned a_trlo = opaque(lds0 + (unsigned)(QR + T::off(4 * h + tq_, 2 * tgi + (tp_ >> 1)) + (tp_ & 1) * 8));
+  const unsigned a_trhi = opaque(lds0 + (unsigned)(QR + T::off(4 * h + tq_ + 8, 2 * tgi + (tp_ >> 1)) + (tp_ & 1) * 8));
+  // dS image of this wave: this lane's key row r (+ 32 g), chunk h (^ 32 s + 16 k for the query chunk 4 s + 2 k + h)
+  const unsigned a_imgw = opaque(lds0 + (unsigned)(IMG + wid * IMG_W + img_off(r, h)));
+  // transposed reads of 4-key x 16-query blocks: keys 8 h + tq_ (+ 4) (+ 16 j), query chunk 4 tgi + tp_
+  const unsigned a_imglo = opaque(lds0 + (unsigned)(IMG + wid * IMG_W + img_off(8 * h + tq_, 4 * tgi + tp_)));
+  const unsigned a_imghi = opaque(lds0 + (unsigned)(IMG + wid * IMG_W + img_off(8 * h + tq_ + 4, 4 * tgi + tp_)));
+  const unsigned a_part = opaque(lds0 + (unsigned)(PART + wid * PART_W + lane * 16));       // this wave's partial tile
+  const unsigned a_red = opaque(lds0 + (unsigned)(PART + wid * 1024 + lane * 16));          // quad `wid` of wave 0's tile
+  const unsigned a_old = opaque(lds0 + (unsigned)(OLD + wid * 1024 + lane * 16));
+  f32x16 zero16;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
+
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int key0 = kb * KB;
+    const unsigned oldbase = kb > 0 ? 0u : DROP;
+    // ---- stage this block's K rows for the transposed reads of the loop-invariant K^T fragments
+    {
+#pragma unroll
+      for (int i = 0; i < KB * 4 / 256; ++i) {
+        const int c = tid + 256 * i;
+        const int row = c >> 2, cc = c & 3;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(kb_ + (size_t)(key0 + row) * rs + 8 * cc);
+        *reinterpret_cast<u32x2*>(smem + STG + img_off(row, 2 * cc)) = u32x2{v[0], v[1]};
+        *reinterpret_cast<u32x2*>(smem + STG + img_off(row, 2 * cc + 1)) = u32x2{v[2], v[3]};
+      }
+    }
+    // ---- this wave's keys: B operands of S (pre-scaled) and dP
+    bf16x8 kS[NG][2], vS[NG][2];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const size_t krow = (size_t)(key0 + wid * KW + 32 * g + r) * rs;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const u32x4 kv = *reinterpret_cast<const u32x4*>(kb_ + krow + 16 * s + 8 * h);
+        const u32x4 vv = *reinterpret_cast<const u32x4*>(vb_ + krow + 16 * s + 8 * h);
+        kS[g][s] = scale_frag(kv, sc2);
+        vS[g][s] = __builtin_bit_cast(bf16x8, vv);
+      }
+    }
+    f32x16 dk0 = zero16, dk1 = zero16, dk2 = zero16, dk3 = zero16, dv0 = zero16, dv1 = zero16, dv2 = zero16, dv3 = zero16;
+    __syncthreads();                              // K staging visible
+    // A operand of dQ^T = K^T dS^T (32x32x16): K^T[row d = r][k = key 16 j + 8 h + e], loop invariant
+    bf16x8 kT[KW / 16];
+#pragma unroll
+    for (int j = 0; j < KW / 16; ++j)
+      kT[j] = cat4(lds_tr_read(smem + STG + wid * IMG_W + img_off(8 * h + tq_, 4 * tgi + tp_) + j * 1024),
+                   lds_tr_read(smem + STG + wid * IMG_W + img_off(8 * h + tq_ + 4, 4 * tgi + tp_) + j * 1024));
+    __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0)
+    __syncthreads();                              // every wave has its K^T fragments: the partial-tile region is free
+
+    // (every load the compiler tracks has returned: without this it carries "loads pending" into the tile loop and waits there
+    // with a vmcnt that also drains the hand-counted LDS-DMA ring)
+    wait_vm<0>();
+    // ---- ring prologue: tiles 0 .. 2, workspace values of tile 0; tiles 0 and 1 complete behind the barrier
+    issue(0, 0, 0);
+    issue(1, 1, 1);
+    issue(2, 2, 2);
+    oldreq(0, 0, oldbase);
+    wait_vm<5>();
+    __builtin_amdgcn_s_barrier();
+
+    // ---- pipeline prologue: fragments of sub-step (0, 0), S / dP of its first key group; everything the first C1 / D / reduce
+    // of the loop consume without a producer is zero or is dropped (the dQ^T partials of "sub-step -1": stores outside the range)
+    f32x16 lse_t, dlt_t, saA, dpA, saB, dpB, dq = zero16;
+    bf16x8 qrow0, qrow1, orow0, orow1, qTa0, qTa1, oTa0, oTa1, qTb0, qTb1, oTb0, oTb1;
+    u32x4 pf0 = {0u, 0u, 0u, 0u}, pf1 = pf0, dsf0 = pf0, dsf1 = pf0;
+    {
+#pragma unroll
+      for (int G = 0; G < 4; ++G) {
+        const f32x4 a = lds_ld<f32x4>(a_const + 32 * G);
+        const f32x4 d = lds_ld<f32x4>(a_const + 256 + 32 * G);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lse_t[4 * G + e] = a[e]; dlt_t[4 * G + e] = d[e]; }
+      }
+      qrow0 = lds_ld<bf16x8>(a_row);
+      orow0 = lds_ld<bf16x8>(a_row + (OR_ - QR));
+      qrow1 = lds_ld<bf16x8>(a_row ^ 32u);
+      orow1 = lds_ld<bf16x8>((a_row ^ 32u) + (OR_ - QR));
+      qTa0 = cat4(lds_tr_ld(a_trlo), lds_tr_ld(a_trhi));
+      oTa0 = cat4(lds_tr_ld(a_trlo + (OR_ - QR)), lds_tr_ld(a_trhi + (OR_ - QR)));
+      qTa1 = cat4(lds_tr_ld(a_trlo + 16 * 64), lds_tr_ld(a_trhi + 16 * 64));
+      oTa1 = cat4(lds_tr_ld(a_trlo + 16 * 64 + (OR_ - QR)), lds_tr_ld(a_trhi + 16 * 64 + (OR_ - QR)));
+      qTb0 = qTb1 = oTb0 = oTb1 = __builtin_bit_cast(bf16x8, pf0);
+      saA = mfma32(qrow0, kS[0][0], lse_t);
+      dpA = mfma32(orow0, vS[0][0], dlt_t);
+      saA = mfma32(qrow1, kS[0][1], saA);
+      dpA = mfma32(orow1, vS[0][1], dpA);
+      saB = zero16; dpB = zero16;
+    }
+
+    // Vector-memory operations of this wave in issue order (vmcnt retires in order): prologue 3 + 3 + 3 + 2; iteration t:
+    // [store of reduce, sub-step 0] [tile t+3: 3] [workspace values of tile t+1: 2] [store of reduce, sub-step 1] = 7.
+    // Iteration t (tile t; t = ntiles is the all-padding tile that drains the pipeline: P = 0 there) needs, before its
+    // mid-tile barrier, tile t+1 complete, and in its reduces the workspace values of tile t-1: both were requested in
+    // iteration t-2 or earlier, so "all but the last iteration's 7" covers them.
+    for (int t = 0; t <= ntiles; ++t) {
+      if (t > 0) wait_vm<7>();
+      const int slot = t & (NB - 1), slotn = (t + 1) & (NB - 1);
+      const unsigned s_pc1 = (unsigned)(slot * 512 + 128), s_x1 = (unsigned)(slot * T::BYTES + 32 * T::ROWB);
+      const unsigned s_pcn = (unsigned)(slotn * 512), s_xn = (unsigned)(slotn * T::BYTES);
+      const unsigned s_oldr = (unsigned)(((t + 2) % NOLD) * 2 * NW * 1024);
+      const unsigned s_redoff0 = t > 0 ? (unsigned)(t - 1) * WS_TILE : DROP;
+      const unsigned s_redoff1 = t > 0 ? (unsigned)(t - 1) * WS_TILE + WS_SUB : DROP;
+      auto issue_tile = [&]() {
+        const int tn = t + LA;
+        issue(tn < ntiles ? tn : tn - ntiles, tn < ntiles ? tn : ntiles, tn & (NB - 1));
+        oldreq(t + 1, (t + 1) % NOLD, oldbase);
+      };
+#include "attn_bwd1w_body.inc"
+    }
+    // ---- dK, dV of this wave's keys (the last MFMAs into them are more than a sub-step behind; the nops keep the read-out of
+    // the accumulators clear of them whatever the compiler places here)
+    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dk0), "+a"(dk1), "+a"(dk2), "+a"(dk3), "+a"(dv0), "+a"(dv1), "+a"(dv2), "+a"(dv3));
+    {
+      const f32x16* dks[4] = {&dk0, &dk1, &dk2, &dk3};
+      const f32x16* dvs[4] = {&dv0, &dv1, &dv2, &dv3};
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        bf16_t* drow = dqkv + ((size_t)b * N + key0 + wid * KW + 32 * g + r) * rs + (size_t)head * HD;
+        const f32x16& dkg = *dks[g];
+        const f32x16& dvg = *dvs[g];
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+          const u32x2 wk = {pack2bf(dkg[4 * G] * scale, dkg[4 * G + 1] * scale), pack2bf(dkg[4 * G + 2] * scale, dkg[4 * G + 3] * scale)};
+          const u32x2 wv = {pack2bf(dvg[4 * G], dvg[4 * G + 1]), pack2bf(dvg[4 * G + 2], dvg[4 * G + 3])};
+          *reinterpret_cast<u32x2*>(drow + (size_t)H * HD + 8 * G + 4 * h) = wk;
+          *reinterpret_cast<u32x2*>(drow + (size_t)2 * H * HD + 8 * G + 4 * h) = wv;
+        }
+      }
+    }
+    // next block: its workspace read-modify-write of a row is done by the same lane as this block's (program order); drain
+    // everything (the surplus tiles of the ring included) before the K staging reuses the partial-tile region
+    wait_vm<0>();
+    __syncthreads();
+  }
+}
+
+}  // namespace octmae
+
+using namespace octmae;
+
+// launcher used by attn_bwd.hip's run_fused<32>
+namespace octmae {
+int launch_attn_bwd_fused1w(const bf16_t* qkv, const bf16_t* dout, const float* rowc, float* dq_ws, bf16_t* dqkv, int B, int N, int NPAD,
+                            int H, int nkb, float scale, hipStream_t st) {
+  static DynLdsOnce once;
+  if (int rc = once.ensure(reinterpret_cast<const void*>(attn_bwd_fused1w_kernel), bwd1w::LDS)) return rc;
+  hipLaunchKernelGGL(attn_bwd_fused1w_kernel, dim3(B * H), dim3(256), bwd1w::LDS, st, qkv, dout, rowc, dq_ws, dqkv, N, NPAD, H, nkb, scale);
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace octmae

@@ -318,6 +318,16 @@ def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, HD: int, scale: float, o
 ATTN_BWD_FUSED = {32: True, 64: True}
 
 
+def set_option(key: str, value: int) -> int:
+    """octmae_set_option: kernel-selection switch for A/B measurements and tests ("attn_bwd_hd32_form": 1 = one wave per SIMD
+    (default), 0 = the two-waves-per-SIMD kernel).  Returns the previous value."""
+    from ._lib import load
+    prev = load().octmae_set_option(key.encode(), int(value))
+    if prev < 0:
+        raise RuntimeError(f"octmae_set_option: unknown key {key!r}")
+    return prev
+
+
 def attn_bwd(qkv, o, dout, lse, B, N, H, HD, scale, fused: Optional[bool] = None):
     """Gradient of attn_fwd w.r.t. the packed qkv.  Algorithmic work ("x3" in total): 4 matrix products =
     8 B H N^2 HD flop (dP, dV, dK, dQ); the recomputation of S is not counted."""

@@ -351,6 +351,41 @@ def test_attention_backward_fused_equals_two_kernel_form_closely():
         assert torch.equal(a, a2)                                       # no atomics: bit-reproducible
 
 
+@pytest.mark.parametrize("N,B,H", [(5121, 1, 2), (1536, 2, 3), (1025, 1, 4), (577, 2, 2), (512, 3, 1), (1281, 2, 16)])
+def test_attention_backward_hd32_both_forms(N, B, H):
+    """head_dim 32 has two main kernels behind octmae_attn_bwd_fused (octmae_set_option "attn_bwd_hd32_form"): one wave per SIMD
+    with 4 x 128 keys per workgroup (csrc/attn_bwd1w.hip, the default) and the round-2 kernel with two waves per SIMD and 8 x 64
+    keys (csrc/attn_bwd.hip).  Same rounding points, different summation order of dQ: both against fp64 on the same bf16
+    operands, against each other, and each bit-reproducible."""
+    HD = 32
+    g = torch.Generator().manual_seed(N + 7 * H)
+    qkv = bf(torch.randn(B * N, 3 * H * HD, generator=g)).to(DEV)
+    do = bf(torch.randn(B * N, H * HD, generator=g)).to(DEV)
+    o, lse = ops.attn_fwd(qkv, B, N, H, HD, HD ** -0.5)
+    qd = qkv.double().requires_grad_(True)
+    o_ref, _ = attn_ref(qd, B, N, H, HD)
+    o_ref.backward(do.double())
+    ref = qd.grad.view(B, N, 3, H * HD)
+    out = {}
+    prev = ops.set_option("attn_bwd_hd32_form", 1)
+    try:
+        for form in (1, 0):
+            ops.set_option("attn_bwd_hd32_form", form)
+            d = ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, HD ** -0.5, fused=True)
+            d2 = ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, HD ** -0.5, fused=True)
+            assert torch.equal(d, d2), form
+            got = d.double().view(B, N, 3, H * HD)
+            errs = {name: rel(got[:, :, i], ref[:, :, i]) for i, name in enumerate("qkv")}
+            print(f"attention backward hd32 form {form} N={N}: " + ", ".join(f"d{k} {v:.2e}" for k, v in errs.items()))
+            assert max(errs.values()) < 1.5e-2, (form, errs)
+            out[form] = d
+    finally:
+        ops.set_option("attn_bwd_hd32_form", prev)
+    a, b_ = out[1].double().view(B, N, 3, H * HD), out[0].double().view(B, N, 3, H * HD)
+    assert torch.equal(out[1].view(B, N, 3, H * HD)[:, :, 1:], out[0].view(B, N, 3, H * HD)[:, :, 1:]) or rel(a[:, :, 1:], b_[:, :, 1:]) < 1e-3
+    assert rel(a[:, :, 0], b_[:, :, 0]) < 3e-3          # dQ: one bf16 rounding of a differently ordered fp32 sum
+
+
 @pytest.mark.parametrize("HD,N", [(64, 333), (32, 1281), (64, 129), (32, 64)])
 def test_attention_backward_fused_row_constants(HD, N):
     """octmae_attn_bwd (dQ kernel computes and publishes the row constants) against the three-launch form
