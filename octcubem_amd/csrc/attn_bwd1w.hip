@@ -29,18 +29,17 @@ using T = Tile<HD>;                                     // 64 rows x 64 B, XOR-s
 constexpr int QR = 0;                                   // Q ring      [NB][4096]
 constexpr int OR_ = QR + NB * T::BYTES;                 // dO ring     [NB][4096]
 constexpr int CR = OR_ + NB * T::BYTES;                 // constants   [NB][2][64] f32
-constexpr int IMG = CR + NB * 512;                      // per wave: dS image [128 keys][32 queries] bf16 (64-byte rows)
-constexpr int IMG_W = KW * 64;
-constexpr int PART = IMG + NW * IMG_W;                  // dQ^T partial tiles [2 sub-steps][NW][4 quads][64 lanes] f32x4
-constexpr int PART_W = 4096;
-constexpr int OLD = PART + 2 * NW * PART_W;             // workspace values   [NOLD tiles][2 sub-tiles][NW][64 lanes] f32x4
+constexpr int IMG = CR + NB * 512;                      // dS images [2 sub-steps][512 keys][32 queries] bf16 (64-byte rows); wave w
+constexpr int IMG_W = KW * 64;                          //   writes rows 128 w .. 128 w + 127, every wave reads all rows (transposed)
+constexpr int IMG_BUF = KB * 64;
+constexpr int OLD = IMG + 2 * IMG_BUF;                  // workspace values   [NOLD tiles][2 sub-tiles][NW][64 lanes] f32x4
 constexpr int LDS = OLD + NOLD * 2 * NW * 1024;
-constexpr int STG = PART;                               // K rows of the block [512][64 B], staged once per block for the K^T reads
-static_assert(KB * 64 <= 2 * NW * PART_W, "K staging must fit the partial-tile region");
+constexpr int STG = IMG;                                // K rows of the block [512][64 B], staged once per block for the K^T reads
 static_assert(LDS <= 160 * 1024, "LDS budget");
-static_assert((CR % 128) == 0 && (IMG % 128) == 0 && (PART % 128) == 0 && (OLD % 128) == 0, "XOR chunk selectors act on address bits 0..6");
+static_assert((CR % 128) == 0 && (IMG % 128) == 0 && (OLD % 128) == 0, "XOR chunk selectors act on address bits 0..6");
 
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
 template <int CNT>
 __device__ __forceinline__ void wait_vm() {
@@ -74,14 +73,35 @@ __device__ __forceinline__ int img_off(int row, int c8) { return row * 64 + ((c8
 // generator pins their last producer), the accumulate chain needs no wait states, and the read-out after the loop sits behind
 // explicit s_nops.
 #define MFMA_ACC(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+// end of a sub-step: this wave's dS image rows are written (LDS operations complete in order: at most the N reads issued after
+// the last image write may still be pending), then the workgroup barrier
 #ifdef ABL_NO_BARRIER
-#define SUBSTEP_END() __builtin_amdgcn_s_waitcnt(0xC07F)
+#define SUBSTEP_END(N) __builtin_amdgcn_s_waitcnt(0xC07F | 0)
 #else
-#define SUBSTEP_END()                        \
-  do {                                       \
-    __builtin_amdgcn_s_waitcnt(0xC07F);      \
-    __builtin_amdgcn_s_barrier();            \
+#define SUBSTEP_END(N)                                            \
+  do {                                                            \
+    __builtin_amdgcn_s_waitcnt(0xC07F | ((N) << 8));              \
+    __builtin_amdgcn_s_barrier();                                 \
   } while (0)
+#endif
+
+// ---- diagnostic build (-DBWD1W_STAMP, make stamp): s_memtime at the start and the middle of every group-step, before the
+// end-of-sub-step wait and behind the barrier; per-wave sums of the 10 intervals of each sub-step (tools/attn_bwd1w_stamps.py).
+// The stamps go to a buffer of their own and no output depends on them.
+#ifdef BWD1W_STAMP
+__device__ unsigned g_bwd1w_stamp[512 * 4 * 2 * 10];
+#define STAMP(k) asm volatile("s_memtime %0" : "=s"(st_[k]))
+#define STAMP_ACCUM(s)                                                                                           \
+  do {                                                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(st_[0]), "+s"(st_[1]), "+s"(st_[2]), "+s"(st_[3]), "+s"(st_[4]), \
+                 "+s"(st_[5]), "+s"(st_[6]), "+s"(st_[7]), "+s"(st_[8]), "+s"(st_[9]));                          \
+    _Pragma("unroll") for (int k_ = 0; k_ < 9; ++k_) acc_[s][k_] += (unsigned)st_[k_ + 1] - (unsigned)st_[k_];  \
+    acc_[s][9] += (unsigned)st_[0] - last_;                                                                      \
+    last_ = (unsigned)st_[9];                                                                                    \
+  } while (0)
+#else
+#define STAMP(k)
+#define STAMP_ACCUM(s)
 #endif
 
 }  // namespace bwd1w
@@ -134,12 +154,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
   };
 
   // ---- dQ workspace of this (batch, head): fp32 [N][32]; rows >= N fall outside the descriptor (loads 0, stores dropped).
-  // Wave w owns register quad w of every dQ^T tile: head dims 8 w + 4 h .. + 3 of query r of the sub-tile.
+  // Wave w owns one 16 x 16 tile of every sub-step's dQ^T[32 head dims][32 queries]: head dims 16 (w & 1) + 4 (lane >> 4) .. + 3
+  // of query 16 (w >> 1) + (lane & 15) of the sub-tile (the C / D layout of the 16x16x32 MFMA).
   float* wsb = dq_ws + (size_t)bh * N * HD;
   const i32x4_t rsW = make_rsrc(wsb, (unsigned)((size_t)N * HD * 4));
   const __amdgpu_buffer_rsrc_t rsWs = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<void*>(((unsigned long long)(unsigned)rsW[1] << 32) | (unsigned)rsW[0]), 0, rsW[2], 0x00020000);
-  const unsigned wsoff = (unsigned)((r * HD + 8 * wid + 4 * h) * 4);
+  const int dt = wid & 1, qt = wid >> 1, g16 = lane >> 4, c16 = lane & 15;
+  const unsigned wsoff = (unsigned)(((16 * qt + c16) * HD + 16 * dt + 4 * g16) * 4);
   constexpr unsigned WS_SUB = 32 * HD * 4, WS_TILE = 64 * HD * 4, DROP = 0x80000000u;   // DROP: an offset outside every descriptor
   // workspace values of this wave's quads of `tile` -> OLD buffer   (2 operations; `base` = DROP in the first key block: zeros)
   auto oldreq = [&](int tile, int buf, unsigned base) {
@@ -156,17 +178,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
   const unsigned a_row = opaque(lds0 + (unsigned)(QR + T::off(r, h)));
   const unsigned a_trlo = opaque(lds0 + (unsigned)(QR + T::off(4 * h + tq_, 2 * tgi + (tp_ >> 1)) + (tp_ & 1) * 8));
   const unsigned a_trhi = opaque(lds0 + (unsigned)(QR + T::off(4 * h + tq_ + 8, 2 * tgi + (tp_ >> 1)) + (tp_ & 1) * 8));
-  // dS image of this wave: this lane's key row r (+ 32 g), chunk h (^ 32 s + 16 k for the query chunk 4 s + 2 k + h)
-  const unsigned a_imgw = opaque(lds0 + (unsigned)(IMG + wid * IMG_W + img_off(r, h)));
-  // transposed reads of 4-key x 16-query blocks: keys 8 h + tq_ (+ 4) (+ 16 j), query chunk 4 tgi + tp_
-  const unsigned a_imglo = opaque(lds0 + (unsigned)(IMG + wid * IMG_W + img_off(8 * h + tq_, 4 * tgi + tp_)));
-  const unsigned a_imghi = opaque(lds0 + (unsigned)(IMG + wid * IMG_W + img_off(8 * h + tq_ + 4, 4 * tgi + tp_)));
-  const unsigned a_part = opaque(lds0 + (unsigned)(PART + wid * PART_W + lane * 16));       // this wave's partial tile
-  const unsigned a_red = opaque(lds0 + (unsigned)(PART + wid * 1024 + lane * 16));          // quad `wid` of wave 0's tile
+  // dS image: this lane's key row 128 wid + r (+ 32 g), chunk h (^ 32 s + 16 k for the query chunk 4 s + 2 k + h) (+ image buffer)
+  const unsigned a_imgw = opaque(lds0 + (unsigned)(IMG + img_off(wid * KW + r, h)));
+  // transposed reads of 4-key x 16-query blocks for the 16x16x32 B operand dS^T[k = key 32 ks + 8 g16 + e][col q = 16 qt + c16]:
+  // keys 8 g16 + tq_ (+ 4) (+ 32 ks), query chunk 4 qt + tp_ (+ image buffer)
+  const unsigned a_imglo = opaque(lds0 + (unsigned)(IMG + img_off(8 * g16 + tq_, 4 * qt + tp_)));
+  const unsigned a_imghi = opaque(lds0 + (unsigned)(IMG + img_off(8 * g16 + tq_ + 4, 4 * qt + tp_)));
   const unsigned a_old = opaque(lds0 + (unsigned)(OLD + wid * 1024 + lane * 16));
   f32x16 zero16;
 #pragma unroll
   for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   for (int kb = 0; kb < nkb; ++kb) {
     const int key0 = kb * KB;
@@ -197,14 +219,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
     }
     f32x16 dk0 = zero16, dk1 = zero16, dk2 = zero16, dk3 = zero16, dv0 = zero16, dv1 = zero16, dv2 = zero16, dv3 = zero16;
     __syncthreads();                              // K staging visible
-    // A operand of dQ^T = K^T dS^T (32x32x16): K^T[row d = r][k = key 16 j + 8 h + e], loop invariant
-    bf16x8 kT[KW / 16];
+    // A operand of dQ^T = K^T dS^T (16x16x32): K^T[row d = 16 dt + c16][k = key 32 ks + 8 g16 + e], all 512 keys, loop invariant
+    bf16x8 kT[KB / 32];
 #pragma unroll
-    for (int j = 0; j < KW / 16; ++j)
-      kT[j] = cat4(lds_tr_read(smem + STG + wid * IMG_W + img_off(8 * h + tq_, 4 * tgi + tp_) + j * 1024),
-                   lds_tr_read(smem + STG + wid * IMG_W + img_off(8 * h + tq_ + 4, 4 * tgi + tp_) + j * 1024));
+    for (int ks = 0; ks < KB / 32; ++ks)
+      kT[ks] = cat4(lds_tr_read(smem + STG + img_off(8 * g16 + tq_, 4 * dt + tp_) + ks * 2048),
+                    lds_tr_read(smem + STG + img_off(8 * g16 + tq_ + 4, 4 * dt + tp_) + ks * 2048));
     __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0)
-    __syncthreads();                              // every wave has its K^T fragments: the partial-tile region is free
+    __syncthreads();                              // every wave has its K^T fragments: the image region is free
 
     // (every load the compiler tracks has returned: without this it carries "loads pending" into the tile loop and waits there
     // with a vmcnt that also drains the hand-counted LDS-DMA ring)
@@ -218,9 +240,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
     __builtin_amdgcn_s_barrier();
 
     // ---- pipeline prologue: fragments of sub-step (0, 0), S / dP of its first key group; everything the first C1 / D / reduce
-    // of the loop consume without a producer is zero or is dropped (the dQ^T partials of "sub-step -1": stores outside the range)
-    f32x16 lse_t, dlt_t, saA, dpA, saB, dpB, dq = zero16;
-    bf16x8 qrow0, qrow1, orow0, orow1, qTa0, qTa1, oTa0, oTa1, qTb0, qTb1, oTb0, oTb1;
+    // of the loop consume without a producer is zero or is dropped (the dQ^T tile of "sub-step -1": a store outside the range)
+    f32x16 lse_a, dlt_a, lse_b = zero16, dlt_b = zero16, saA, dpA, saB, dpB;
+    f32x4 dqA = zero4, dqB = zero4;
+    bf16x8 qrowa0, qrowa1, orowa0, orowa1, qrowb0, qrowb1, orowb0, orowb1, qTa0, qTa1, oTa0, oTa1, qTb0, qTb1, oTb0, oTb1;
     u32x4 pf0 = {0u, 0u, 0u, 0u}, pf1 = pf0, dsf0 = pf0, dsf1 = pf0;
     {
 #pragma unroll
@@ -228,21 +251,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
         const f32x4 a = lds_ld<f32x4>(a_const + 32 * G);
         const f32x4 d = lds_ld<f32x4>(a_const + 256 + 32 * G);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { lse_t[4 * G + e] = a[e]; dlt_t[4 * G + e] = d[e]; }
+        for (int e = 0; e < 4; ++e) { lse_a[4 * G + e] = a[e]; dlt_a[4 * G + e] = d[e]; }
       }
-      qrow0 = lds_ld<bf16x8>(a_row);
-      orow0 = lds_ld<bf16x8>(a_row + (OR_ - QR));
-      qrow1 = lds_ld<bf16x8>(a_row ^ 32u);
-      orow1 = lds_ld<bf16x8>((a_row ^ 32u) + (OR_ - QR));
+      qrowa0 = lds_ld<bf16x8>(a_row);
+      orowa0 = lds_ld<bf16x8>(a_row + (OR_ - QR));
+      qrowa1 = lds_ld<bf16x8>(a_row ^ 32u);
+      orowa1 = lds_ld<bf16x8>((a_row ^ 32u) + (OR_ - QR));
       qTa0 = cat4(lds_tr_ld(a_trlo), lds_tr_ld(a_trhi));
       oTa0 = cat4(lds_tr_ld(a_trlo + (OR_ - QR)), lds_tr_ld(a_trhi + (OR_ - QR)));
       qTa1 = cat4(lds_tr_ld(a_trlo + 16 * 64), lds_tr_ld(a_trhi + 16 * 64));
       oTa1 = cat4(lds_tr_ld(a_trlo + 16 * 64 + (OR_ - QR)), lds_tr_ld(a_trhi + 16 * 64 + (OR_ - QR)));
-      qTb0 = qTb1 = oTb0 = oTb1 = __builtin_bit_cast(bf16x8, pf0);
-      saA = mfma32(qrow0, kS[0][0], lse_t);
-      dpA = mfma32(orow0, vS[0][0], dlt_t);
-      saA = mfma32(qrow1, kS[0][1], saA);
-      dpA = mfma32(orow1, vS[0][1], dpA);
+      qTb0 = qTb1 = oTb0 = oTb1 = qrowb0 = qrowb1 = orowb0 = orowb1 = __builtin_bit_cast(bf16x8, pf0);
+      saA = mfma32(qrowa0, kS[0][0], lse_a);
+      dpA = mfma32(orowa0, vS[0][0], dlt_a);
+      saA = mfma32(qrowa1, kS[0][1], saA);
+      dpA = mfma32(orowa1, vS[0][1], dpA);
       saB = zero16; dpB = zero16;
     }
 
@@ -251,6 +274,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
     // Iteration t (tile t; t = ntiles is the all-padding tile that drains the pipeline: P = 0 there) needs, before its
     // mid-tile barrier, tile t+1 complete, and in its reduces the workspace values of tile t-1: both were requested in
     // iteration t-2 or earlier, so "all but the last iteration's 7" covers them.
+#ifdef BWD1W_STAMP
+    unsigned long long st_[10];
+    unsigned acc_[2][10] = {};
+    unsigned last_ = 0;
+    STAMP(9);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(st_[9]));
+    last_ = (unsigned)st_[9];
+#endif
     for (int t = 0; t <= ntiles; ++t) {
       if (t > 0) wait_vm<7>();
       const int slot = t & (NB - 1), slotn = (t + 1) & (NB - 1);
@@ -266,6 +297,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
       };
 #include "attn_bwd1w_body.inc"
     }
+#ifdef BWD1W_STAMP
+    if (kb == 1 && lane == 0 && blockIdx.x < 512)
+      for (int s_ = 0; s_ < 2; ++s_)
+        for (int k_ = 0; k_ < 10; ++k_) g_bwd1w_stamp[((blockIdx.x * 4 + wid) * 2 + s_) * 10 + k_] = acc_[s_][k_];
+#endif
     // ---- dK, dV of this wave's keys (the last MFMAs into them are more than a sub-step behind; the nops keep the read-out of
     // the accumulators clear of them whatever the compiler places here)
     asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dk0), "+a"(dk1), "+a"(dk2), "+a"(dk3), "+a"(dv0), "+a"(dv1), "+a"(dv2), "+a"(dv3));
@@ -296,6 +332,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
 }  // namespace octmae
 
 using namespace octmae;
+
+#ifdef BWD1W_STAMP
+extern "C" int octmae_debug_bwd1w_stamps(void* host, int nbytes) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(octmae::bwd1w::g_bwd1w_stamp), (size_t)nbytes);
+}
+#endif
 
 // launcher used by attn_bwd.hip's run_fused<32>
 namespace octmae {
