@@ -22,7 +22,7 @@ extern "C" {
 
 /* The ONE place the ABI number lives: octmae_abi_version() returns it (csrc/probe.hip), octcubem_amd/_lib.py parses it
  * from this header and refuses a library that reports another number, __graft_entry__.build() and the tests compare the two.
- * 4: octmae_attn_bwd_dq_rowconst.  5: octmae_comm_* (RCCL), octmae_attn_bwd_fused + workspace query.  7: octmae_set_option. */
+ * 4: octmae_attn_bwd_dq_rowconst.  5: octmae_comm_* (RCCL), octmae_attn_bwd_fused + workspace query.  7: octmae_set_option, octmae_scatter_add_rows, octmae_dec_assemble_bwd. */
 #define OCTMAE_ABI_VERSION 7
 int octmae_abi_version(void);
 
@@ -149,6 +149,16 @@ int octmae_dec_assemble(const void* emb_bf16, const float* mask_token, const flo
 /* out bf16[b*n+i][:] = src f32[b][1+ids[b][i]][:]  (backward of both assemblies w.r.t. the token rows) */
 int octmae_gather_rows_cast(const float* src, const long long* ids, void* out_bf16, int B, int n, int src_rows, int D,
                             void* stream);
+/* backward of the keep-gather w.r.t. the positional table (autograd of torch.gather at models_mae_joint_res_flash_attn.py:442-447;
+ * ATen: index_add_): out f32 [L][D] (+)= sum over samples b that kept token l (ids_restore[b][l] < nkeep) of
+ * src f32 [b][row0 + ids_restore[b][l]][:], src has src_rows rows per sample.  Deterministic (ascending b), no atomics. */
+int octmae_scatter_add_rows(const float* src, const long long* ids_restore, float* out, int B, int nkeep, int L, int D,
+                            int src_rows, int row0, int accumulate, void* stream);
+/* backward of the decoder assembly w.r.t. decoder_pos_embed and mask_token in one pass over dx f32 [B][1 + L][D]
+ * (models_mae_joint_res_flash_attn.py:515-573 under autograd): ddpos [L][D] = sum_b dx[b][1 + l], dmask_part [L][D] = the same sum
+ * over the samples in which token l was masked; the mask-token gradient is the column sum of dmask_part. */
+int octmae_dec_assemble_bwd(const float* dx, const long long* ids_restore, float* ddpos, float* dmask_part, int B, int nkeep, int L,
+                            int D, void* stream);
 /* fused patchify + per-token MSE, models_mae_joint_res_flash_attn.py:289-314, :613-650.  pred f32 [B][L+1][PD]
  * (row 0 = cls, ignored); loss_tok f32 [B][L].  frame_idx int32 [pred_t_dim] or NULL (identity). */
 int octmae_mse_fwd(const float* pred, const float* imgs, const int* frame_idx, float* loss_tok, int B, int C, int T, int H,

@@ -40,6 +40,8 @@ SIGNATURES = {
     "octmae_enc_assemble": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "octmae_dec_assemble": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "octmae_gather_rows_cast": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "octmae_scatter_add_rows": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "octmae_dec_assemble_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "octmae_mse_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "octmae_mse_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "octmae_mt_chunk_elems": [],

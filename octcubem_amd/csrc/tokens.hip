@@ -181,6 +181,93 @@ __global__ __launch_bounds__(256) void dec_assemble_kernel(const bf16_t* __restr
 // Row gather with fp32 -> bf16 cast: out[b*n + i][:] = src[b][1 + ids[b][i]][:]  (src rows include the cls slot).
 // Backward of both assemblies w.r.t. the token matrix: ids = ids_keep (a permutation prefix), so a pure gather.
 // ids == nullptr means identity (out[b*n+i] = src[b][1+i]).
+// ---------------------------------------------------------------------------------------------
+// Backward of a row gather as a GATHER (scatter_add_rows): out[l][:] (+)= sum over samples b with ids_restore[b][l] < nkeep of
+// src[b][row0 + ids_restore[b][l]][:].  A kept token's source row is its rank in the shuffle, so the positional table's
+// gradient needs no atomics: one workgroup per table row l collects the samples that kept l (deterministic compaction, ascending
+// b) and sums their rows in that order, four row loads in flight.  Replaces ATen's index_add_ (fp32 atomics in arrival order).
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, const long long* __restrict__ ids_restore,
+                                                               float* __restrict__ out, int B, int nkeep, int L, int D,
+                                                               int src_rows, int row0, int accumulate) {
+  __shared__ int rows[1024];                 // compact list: source row index (b * src_rows + row0 + rank) of every keeper
+  __shared__ int wave_cnt[4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int d4 = D >> 2;
+  for (int l = blockIdx.x; l < L; l += gridDim.x) {
+    int total = 0;
+    for (int b0 = 0; b0 < B; b0 += 256) {    // B <= 1024 (checked by the launcher)
+      const int b = b0 + tid;
+      int rank = nkeep;
+      if (b < B) rank = (int)ids_restore[(size_t)b * L + l];
+      const bool keep = rank < nkeep;
+      const unsigned long long m = __ballot(keep);
+      if (lane == 0) wave_cnt[wid] = __popcll(m);
+      __syncthreads();
+      int base = total;
+      for (int w = 0; w < wid; ++w) base += wave_cnt[w];
+      if (keep) rows[base + __popcll(m & ((1ull << lane) - 1ull))] = b * src_rows + row0 + rank;
+      total += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+      __syncthreads();
+    }
+    for (int c = tid; c < d4; c += 256) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (accumulate) acc = *reinterpret_cast<const f32x4*>(out + (size_t)l * D + 4 * c);
+      int i = 0;
+      for (; i + 4 <= total; i += 4) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (size_t)rows[i] * D + 4 * c);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + (size_t)rows[i + 1] * D + 4 * c);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + (size_t)rows[i + 2] * D + 4 * c);
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(src + (size_t)rows[i + 3] * D + 4 * c);
+        acc += v0; acc += v1; acc += v2; acc += v3;
+      }
+      for (; i < total; ++i) acc += *reinterpret_cast<const f32x4*>(src + (size_t)rows[i] * D + 4 * c);
+      *reinterpret_cast<f32x4*>(out + (size_t)l * D + 4 * c) = acc;
+    }
+    __syncthreads();                         // the list is rebuilt for the next row
+  }
+}
+
+// Backward of the decoder assembly w.r.t. the positional table and the mask token in ONE pass over the gradient
+// (models_mae_joint_res_flash_attn.py:515-573 under autograd): ddpos[l][:] = sum_b dx[b][1 + l][:] and, per table row,
+// dmask_part[l][:] = sum over the samples in which token l was masked (ids_restore[b][l] >= nkeep); the caller folds dmask_part
+// over l with octmae_colsum_accum.  (ATen: a [B, L, D] multiply by the mask, two reductions and the copies between them.)
+__global__ __launch_bounds__(256) void dec_assemble_bwd_kernel(const float* __restrict__ dx, const long long* __restrict__ ids_restore,
+                                                               float* __restrict__ ddpos, float* __restrict__ dmask_part, int B,
+                                                               int nkeep, int L, int D) {
+  __shared__ unsigned char masked[1024];
+  const int tid = threadIdx.x;
+  const int d4 = D >> 2;
+  for (int l = blockIdx.x; l < L; l += gridDim.x) {
+    for (int b = tid; b < B; b += 256) masked[b] = ids_restore[(size_t)b * L + l] >= nkeep ? 1 : 0;
+    __syncthreads();
+    for (int c = tid; c < d4; c += 256) {
+      f32x4 all = {0.f, 0.f, 0.f, 0.f}, msk = all;
+      const float* col = dx + ((size_t)1 + l) * D + 4 * c;
+      const size_t bs = (size_t)(L + 1) * D;
+      int b = 0;
+      for (; b + 4 <= B; b += 4) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(col + (size_t)b * bs);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(col + (size_t)(b + 1) * bs);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(col + (size_t)(b + 2) * bs);
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(col + (size_t)(b + 3) * bs);
+        all += v0; all += v1; all += v2; all += v3;
+        if (masked[b]) msk += v0;
+        if (masked[b + 1]) msk += v1;
+        if (masked[b + 2]) msk += v2;
+        if (masked[b + 3]) msk += v3;
+      }
+      for (; b < B; ++b) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(col + (size_t)b * bs);
+        all += v;
+        if (masked[b]) msk += v;
+      }
+      *reinterpret_cast<f32x4*>(ddpos + (size_t)l * D + 4 * c) = all;
+      *reinterpret_cast<f32x4*>(dmask_part + (size_t)l * D + 4 * c) = msk;
+    }
+    __syncthreads();
+  }
+}
+
 template <typename IdxT>
 __global__ __launch_bounds__(256) void gather_rows_cast_kernel(const float* __restrict__ src, const IdxT* __restrict__ ids,
                                                                bf16_t* __restrict__ out, int B, int n, int src_rows, int D) {
@@ -396,6 +483,24 @@ extern "C" int octmae_gather_rows_cast(const float* src, const long long* ids, v
   const size_t total = (size_t)B * n * (D / 8);
   hipLaunchKernelGGL(gather_rows_cast_kernel<long long>, dim3(grid_for(total, 256, 8192)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), src, ids, reinterpret_cast<bf16_t*>(out_bf16), B, n, src_rows, D);
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int octmae_scatter_add_rows(const float* src, const long long* ids_restore, float* out, int B, int nkeep, int L, int D,
+                                       int src_rows, int row0, int accumulate, void* stream) {
+  OCTMAE_CHECK_ARG(src && ids_restore && out && B > 0 && B <= 1024 && nkeep >= 0 && L > 0 && D > 0 && (D & 3) == 0 && src_rows >= row0 + nkeep && row0 >= 0);
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(L < 65535 ? L : 65535), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, ids_restore, out,
+                     B, nkeep, L, D, src_rows, row0, accumulate);
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int octmae_dec_assemble_bwd(const float* dx, const long long* ids_restore, float* ddpos, float* dmask_part, int B, int nkeep,
+                                       int L, int D, void* stream) {
+  OCTMAE_CHECK_ARG(dx && ids_restore && ddpos && dmask_part && B > 0 && B <= 1024 && nkeep >= 0 && L > 0 && D > 0 && (D & 3) == 0);
+  hipLaunchKernelGGL(dec_assemble_bwd_kernel, dim3(L < 65535 ? L : 65535), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dx, ids_restore, ddpos,
+                     dmask_part, B, nkeep, L, D);
   OCTMAE_LAUNCH_CHECK();
   return 0;
 }

@@ -262,7 +262,7 @@ class MaskedAutoencoderViT(nn.Module):
         mask, ids_restore, ids_keep = self.random_masking_ids(N, L, mask_ratio, imgs.device, noise)
         tok = pe_mod.embed_tokens(imgs, ids_keep)                                    # bf16 [N*nkeep, D]
         pos = self._pos_table(self.pos_embed_spatial, self.pos_embed_temporal, high_res, t_actual)
-        x = ops.EncAssembleFn.apply(tok, pos, self.cls_token, self.pos_embed_class, ids_keep)   # fp32 [N, 1+nkeep, D]
+        x = ops.EncAssembleFn.apply(tok, pos, self.cls_token, self.pos_embed_class, ids_keep, ids_restore)   # fp32 [N, 1+nkeep, D]
         x = self._run_blocks(self.blocks, x)
         x = layer_norm(self.norm, x)                                                  # bf16
         x = x[:, 1:, :]

@@ -149,7 +149,7 @@ class MaskedAutoencoderViT(nn.Module):
         mask, ids_restore, ids_keep = ops.random_masking_ids(noise.to(device=x.device, dtype=torch.float32).contiguous(), len_keep)
         tok = self.patch_embed.embed_tokens(x, ids_keep)                               # kept patches only (output-identical)
         pe = self.pos_embed[0]
-        xs = ops.EncAssembleFn.apply(tok, pe[1:], self.cls_token, pe[:1].view(1, 1, -1), ids_keep)   # fp32 [N, 1+keep, D]
+        xs = ops.EncAssembleFn.apply(tok, pe[1:], self.cls_token, pe[:1].view(1, 1, -1), ids_keep, ids_restore)   # fp32 [N, 1+keep, D]
         xs = self._run_blocks(self.blocks, xs)
         xs = layer_norm(self.norm, xs)
         self._ids_keep = ids_keep

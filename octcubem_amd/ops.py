@@ -664,10 +664,13 @@ class BlockFn(torch.autograd.Function):
 
 
 class EncAssembleFn(torch.autograd.Function):
-    """cls concat + gathered positional embedding (models_mae_joint_res_flash_attn.py:409-478)."""
+    """cls concat + gathered positional embedding (models_mae_joint_res_flash_attn.py:409-478).
+    ``ids_restore`` (the masking's inverse permutation, [B, L]) lets the backward build the positional table's gradient as a
+    deterministic gather (octmae_scatter_add_rows) instead of ATen's atomic index_add_; without it (the ViT models, where every
+    token is kept in order) the ATen path is used."""
 
     @staticmethod
-    def forward(ctx, tok, pos, cls, pos_cls, ids_keep):
+    def forward(ctx, tok, pos, cls, pos_cls, ids_keep, ids_restore=None):
         Bn, nkeep = ids_keep.shape
         D = tok.shape[-1]
         _chk(tok, BF16, "tokens")
@@ -675,22 +678,30 @@ class EncAssembleFn(torch.autograd.Function):
         x = torch.empty((Bn, nkeep + 1, D), dtype=F32, device=tok.device)
         call("octmae_enc_assemble", tok.data_ptr(), pos2.data_ptr(), cls.data_ptr(), pos_cls.data_ptr(), ids_keep.data_ptr(),
              x.data_ptr(), Bn, nkeep, D, _stream())
-        ctx.save_for_backward(ids_keep)
+        if ids_restore is not None and (ids_restore.shape[0] != Bn or ids_restore.shape[1] != pos2.shape[0] or Bn > 1024 or D % 4):
+            ids_restore = None
+        ctx.save_for_backward(ids_keep, ids_restore if ids_restore is not None else ids_keep.new_empty(0))
+        ctx.has_restore = ids_restore is not None
         ctx.pos_shape, ctx.cls_shape, ctx.pc_shape = pos.shape, cls.shape, pos_cls.shape
         return x
 
     @staticmethod
     def backward(ctx, dx):
-        (ids_keep,) = ctx.saved_tensors
+        ids_keep, ids_restore = ctx.saved_tensors
         dx = dx.contiguous()
         Bn, n1, D = dx.shape
         nkeep = n1 - 1
         dtok = torch.empty((Bn * nkeep, D), dtype=BF16, device=dx.device)
         call("octmae_gather_rows_cast", dx.data_ptr(), None, dtok.data_ptr(), Bn, nkeep, n1, D, _stream())
-        dpos = torch.zeros(ctx.pos_shape, dtype=F32, device=dx.device)
-        dpos.view(-1, D).index_add_(0, ids_keep.reshape(-1), dx[:, 1:, :].reshape(-1, D))
+        if ctx.has_restore:
+            L = ids_restore.shape[1]
+            dpos = torch.empty(ctx.pos_shape, dtype=F32, device=dx.device)
+            call("octmae_scatter_add_rows", dx.data_ptr(), ids_restore.data_ptr(), dpos.data_ptr(), Bn, nkeep, L, D, n1, 1, 0, _stream())
+        else:
+            dpos = torch.zeros(ctx.pos_shape, dtype=F32, device=dx.device)
+            dpos.view(-1, D).index_add_(0, ids_keep.reshape(-1), dx[:, 1:, :].reshape(-1, D))
         dc = dx[:, 0, :].sum(0)
-        return dtok, dpos, dc.view(ctx.cls_shape), dc.view(ctx.pc_shape).clone(), None
+        return dtok, dpos, dc.view(ctx.cls_shape), dc.view(ctx.pc_shape).clone(), None, None
 
 
 class DecAssembleFn(torch.autograd.Function):
@@ -726,10 +737,20 @@ class DecAssembleFn(torch.autograd.Function):
         else:
             demb = torch.empty((Bn * nkeep, D), dtype=BF16, device=dx.device)
             call("octmae_gather_rows_cast", dx.data_ptr(), ids_keep.data_ptr(), demb.data_ptr(), Bn, nkeep, L1, D, _stream())
-        body = dx[:, 1:, :]
-        masked = (ids_restore >= nkeep).to(F32).unsqueeze(-1)
-        dmask = (body * masked).sum((0, 1))
-        ddpos = body.sum(0)
+        if Bn <= 1024 and D % 4 == 0:
+            # one pass over dx: positional-table gradient and, per table row, the sum over the samples that masked it
+            L = L1 - 1
+            ddpos = torch.empty((L, D), dtype=F32, device=dx.device)
+            part = torch.empty((L, D), dtype=F32, device=dx.device)
+            call("octmae_dec_assemble_bwd", dx.data_ptr(), ids_restore.data_ptr(), ddpos.data_ptr(), part.data_ptr(), Bn, nkeep, L, D,
+                 _stream())
+            dmask = torch.zeros(D, dtype=F32, device=dx.device)
+            colsum_accum(part, dmask)
+        else:
+            body = dx[:, 1:, :]
+            masked = (ids_restore >= nkeep).to(F32).unsqueeze(-1)
+            dmask = (body * masked).sum((0, 1))
+            ddpos = body.sum(0)
         dc = dx[:, 0, :].sum(0)
         return (demb, dmask.view(ms), ddpos.view(ps), None if cs is None else dc.view(cs), dc.view(pcs).clone(), None, None)
 

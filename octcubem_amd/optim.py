@@ -78,11 +78,19 @@ class FusedAdamW(torch.optim.Optimizer):
         self._grad_scale = scale
 
     def zero_grad(self, set_to_none: bool = False):
-        """Gradients are views of one arena: they are zeroed in place, never detached."""
-        for group in self.param_groups:
-            for p in group["params"]:
-                if p.grad is not None:
-                    p.grad.zero_()
+        """Gradients are views of one arena: they are zeroed in place, never detached -- and when every gradient of this
+        optimizer is a view of ONE flat buffer (the model's gradient arena), with a single fill of that buffer instead of one
+        launch per parameter (~500 per step for ViT-L)."""
+        grads = [p.grad for group in self.param_groups for p in group["params"] if p.grad is not None]
+        if not grads:
+            return
+        base = grads[0]._base
+        if base is not None and base.dim() == 1 and all(g._base is base for g in grads) and \
+                sum(g.numel() for g in grads) * 2 >= base.numel():
+            base.zero_()
+            return
+        for g in grads:
+            g.zero_()
 
     @torch.no_grad()
     def step(self, closure=None):

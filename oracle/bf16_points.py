@@ -81,10 +81,10 @@ def dgelu_poly(x):
     return u * q + 0.5
 
 
-def block_forward_backward(P: Dict[str, torch.Tensor], x: torch.Tensor, dx3: torch.Tensor, num_heads: int, eps: float = 1e-6,
-                           fused_bwd: bool = True, exact_gelu: bool = False, poly_dgelu: bool = False):
-    """P: the Block's parameters by their reference names (norm1.weight, attn.q.weight, ..., mlp.fc2.bias), fp32.
-    x, dx3: [B, N, C] fp32.  Returns (x3, dx, grads) in float64."""
+def block_forward(P: Dict[str, torch.Tensor], x: torch.Tensor, num_heads: int, eps: float = 1e-6, exact_gelu: bool = False):
+    """Forward of one Block with the HIP path's roundings.  P: the Block's parameters by their reference names
+    (norm1.weight, attn.q.weight, ..., mlp.fc2.bias); x [B, N, C].  Returns (x3 float64, saved) -- `saved` is what
+    block_backward needs."""
     B, N, C = x.shape
     H = num_heads
     hd = C // H
@@ -92,12 +92,10 @@ def block_forward_backward(P: Dict[str, torch.Tensor], x: torch.Tensor, dx3: tor
     F = torch.float32
     sc2 = torch.tensor(scale, dtype=F) * torch.tensor(LOG2E, dtype=F)      # the kernels form scale*log2e as an fp32 product
     p = {k: v.to(D) for k, v in P.items()}
-    x = x.to(D); dx3 = dx3.to(D)
+    x = x.to(D)
     wqkv = bf(torch.cat([p["attn.q.weight"], p["attn.k.weight"], p["attn.v.weight"]], 0))
     bqkv = torch.cat([p["attn.q.bias"], p["attn.k.bias"], p["attn.v.bias"]], 0)
     wp, w1, w2 = bf(p["attn.proj.weight"]), bf(p["mlp.fc1.weight"]), bf(p["mlp.fc2.weight"])
-
-    # ---------------- forward
     y1f, xh1, rs1 = ln_fwd(x, p["norm1.weight"], p["norm1.bias"], eps)
     y1 = bf(y1f)
     qkv = bf(y1 @ wqkv.T + bqkv)                                            # [B, N, 3C]
@@ -116,17 +114,36 @@ def block_forward_backward(P: Dict[str, torch.Tensor], x: torch.Tensor, dx3: tor
     pre = bf(y2 @ w1.T + p["mlp.fc1.bias"])
     act = bf(gelu(pre) if exact_gelu else gelu_poly(pre))
     x3 = x2 + act @ w2.T + p["mlp.fc2.bias"]
+    saved = dict(p=p, B=B, N=N, C=C, H=H, hd=hd, scale=scale, sc2=sc2, wqkv=wqkv, wp=wp, w1=w1, w2=w2, xh1=xh1, rs1=rs1, y1=y1,
+                 q=q, k=k, v=v, qs=qs, o=o, o2=o2, lse=lse, xh2=xh2, rs2=rs2, y2=y2, pre=pre, act=act)
+    return x3, saved
 
-    # ---------------- backward
+
+def block_backward(saved, dx3: torch.Tensor, fused_bwd: bool = True, poly_dgelu: bool = False):
+    """Backward of one Block with the HIP path's roundings: dx3 [B, N, C] (the fp32 gradient of the block output).
+    Returns (dx float64, grads by reference parameter name)."""
+    s = saved
+    p, B, N, C, H, hd, scale, sc2 = s["p"], s["B"], s["N"], s["C"], s["H"], s["hd"], s["scale"], s["sc2"]
+    wqkv, wp, w1, w2 = s["wqkv"], s["wp"], s["w1"], s["w2"]
+    q, k, v, qs, o, o2, lse, pre, act, y1, y2 = s["q"], s["k"], s["v"], s["qs"], s["o"], s["o2"], s["lse"], s["pre"], s["act"], s["y1"], s["y2"]
+    F = torch.float32
+    dx3 = dx3.to(D)
     G = {}
     d3b = bf(dx3)
     G["mlp.fc2.weight"] = (d3b.reshape(-1, C).T @ act.reshape(-1, act.shape[-1]))
     G["mlp.fc2.bias"] = dx3.reshape(-1, C).sum(0)
-    dpre = bf(bf(d3b @ w2) * (dgelu_poly(pre) if poly_dgelu else dgelu(pre)))
+    # fc2 dgrad x GELU': the 256-tile GEMM kernel rounds the product to bf16 on its way through the epilogue's LDS transpose and
+    # multiplies the ROUNDED value by gelu'(pre) (two roundings); the 128-tile kernel -- taken when a dimension of the GEMM is
+    # below 256 (csrc/gemm.hip `big`: here rows B * N < 256 or hidden < 256 or C % 64 != 0) -- multiplies its fp32 accumulator
+    # and rounds once
+    dg = dgelu_poly(pre) if poly_dgelu else dgelu(pre)
+    hidden = w1.shape[0]
+    big = hidden >= 256 and B * N >= 256 and C % 64 == 0
+    dpre = bf(bf(d3b @ w2) * dg) if big else bf((d3b @ w2) * dg)
     G["mlp.fc1.bias"] = dpre.reshape(-1, dpre.shape[-1]).sum(0)
     G["mlp.fc1.weight"] = dpre.reshape(-1, dpre.shape[-1]).T @ y2.reshape(-1, C)
     dy2 = bf(dpre @ w1)
-    dln2, G["norm2.weight"], G["norm2.bias"] = ln_bwd(dy2, xh2, rs2, p["norm2.weight"])
+    dln2, G["norm2.weight"], G["norm2.bias"] = ln_bwd(dy2, s["xh2"], s["rs2"], p["norm2.weight"])
     dx2 = dx3 + dln2
     dx2b = bf(dx2)
     G["attn.proj.bias"] = dx2.reshape(-1, C).sum(0)
@@ -152,6 +169,15 @@ def block_forward_backward(P: Dict[str, torch.Tensor], x: torch.Tensor, dx3: tor
         G[f"attn.{nme}.weight"] = gw[i * C:(i + 1) * C]
         G[f"attn.{nme}.bias"] = gb[i * C:(i + 1) * C]
     dy1 = bf(dqkv @ wqkv)
-    dln1, G["norm1.weight"], G["norm1.bias"] = ln_bwd(dy1, xh1, rs1, p["norm1.weight"])
+    dln1, G["norm1.weight"], G["norm1.bias"] = ln_bwd(dy1, s["xh1"], s["rs1"], p["norm1.weight"])
     dx = dx2 + dln1
+    return dx, G
+
+
+def block_forward_backward(P: Dict[str, torch.Tensor], x: torch.Tensor, dx3: torch.Tensor, num_heads: int, eps: float = 1e-6,
+                           fused_bwd: bool = True, exact_gelu: bool = False, poly_dgelu: bool = False):
+    """P: the Block's parameters by their reference names (norm1.weight, attn.q.weight, ..., mlp.fc2.bias), fp32.
+    x, dx3: [B, N, C] fp32.  Returns (x3, dx, grads) in float64."""
+    x3, saved = block_forward(P, x, num_heads, eps, exact_gelu)
+    dx, G = block_backward(saved, dx3, fused_bwd, poly_dgelu)
     return x3, dx, G

@@ -487,6 +487,54 @@ def test_patch_gather_and_embed_vs_conv3d():
     assert torch.equal(pat3.cpu(), exp3.to(BF16))
 
 
+@pytest.mark.parametrize("B,L,nkeep,D", [(3, 40, 10, 64), (128, 320, 80, 512), (5, 17, 17, 128), (4, 33, 0, 32), (300, 50, 12, 16)])
+def test_assembly_backward_kernels_vs_aten(B, L, nkeep, D):
+    """octmae_scatter_add_rows (positional-table gradient of the keep-gather as a deterministic gather over ids_restore) against
+    ATen's index_add_, and octmae_dec_assemble_bwd (decoder positional table + per-row mask-token partial sums in one pass)
+    against the masked multiply + two reductions it replaces; both through the autograd Functions as well."""
+    from octcubem_amd._lib import call
+    g = torch.Generator().manual_seed(B * 7 + L)
+    noise = torch.rand(B, L, generator=g)
+    ids_shuffle = torch.argsort(noise, dim=1)
+    ids_restore = torch.argsort(ids_shuffle, dim=1).to(DEV)
+    ids_keep = ids_shuffle[:, :nkeep].contiguous().to(DEV)
+    dx = torch.randn(B, 1 + nkeep, D, generator=g).to(DEV)
+    out = torch.full((L, D), 7.0, device=DEV)
+    call("octmae_scatter_add_rows", dx.data_ptr(), ids_restore.data_ptr(), out.data_ptr(), B, nkeep, L, D, 1 + nkeep, 1, 0,
+         torch.cuda.current_stream().cuda_stream)
+    ref = torch.zeros(L, D, dtype=torch.float64, device=DEV)
+    if nkeep:
+        ref.index_add_(0, ids_keep.reshape(-1), dx[:, 1:, :].reshape(-1, D).double())
+    assert float((out.double() - ref).abs().max()) <= 1e-5 * (1.0 + float(ref.abs().max()))
+    out2 = out.clone()
+    call("octmae_scatter_add_rows", dx.data_ptr(), ids_restore.data_ptr(), out2.data_ptr(), B, nkeep, L, D, 1 + nkeep, 1, 1,
+         torch.cuda.current_stream().cuda_stream)
+    assert float((out2.double() - 2 * ref).abs().max()) <= 2e-5 * (1.0 + float(ref.abs().max()))      # accumulate = 1
+    again = torch.empty_like(out)
+    call("octmae_scatter_add_rows", dx.data_ptr(), ids_restore.data_ptr(), again.data_ptr(), B, nkeep, L, D, 1 + nkeep, 1, 0,
+         torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(again, out)                                                                     # fixed summation order
+    dxd = torch.randn(B, 1 + L, D, generator=g).to(DEV)
+    ddpos = torch.empty(L, D, device=DEV); part = torch.empty(L, D, device=DEV)
+    call("octmae_dec_assemble_bwd", dxd.data_ptr(), ids_restore.data_ptr(), ddpos.data_ptr(), part.data_ptr(), B, nkeep, L, D,
+         torch.cuda.current_stream().cuda_stream)
+    body = dxd[:, 1:, :].double()
+    masked = (ids_restore >= nkeep).double().unsqueeze(-1)
+    assert float((ddpos.double() - body.sum(0)).abs().max()) <= 1e-5 * (1.0 + float(body.sum(0).abs().max()))
+    assert float((part.double() - (body * masked).sum(0)).abs().max()) <= 1e-5 * (1.0 + float(body.abs().sum(0).max()))
+    if B <= 1024 and nkeep > 0:
+        # through autograd: EncAssembleFn with and without ids_restore give the same table gradient
+        tok = torch.randn(B * nkeep, D, generator=g).to(DEV).to(BF16)
+        outs = []
+        for use in (True, False):
+            pos = torch.randn(L, D, generator=torch.Generator().manual_seed(1)).to(DEV).requires_grad_(True)
+            cls = torch.zeros(1, 1, D, device=DEV, requires_grad=True); pc = torch.zeros(1, 1, D, device=DEV, requires_grad=True)
+            x = ops.EncAssembleFn.apply(tok, pos, cls, pc, ids_keep, ids_restore if use else None)
+            x.backward(dx)
+            outs.append(pos.grad.clone())
+        assert float((outs[0] - outs[1]).abs().max()) <= 1e-4 * (1.0 + float(outs[1].abs().max()))
+
+
 @pytest.mark.parametrize("norm_pix", [False, True])
 def test_patch_mse_fwd_bwd(norm_pix):
     cfg = O.MAEConfig(input_size=32, in_chans=1, num_frames=6, t_patch_size=3, pred_t_dim=6, high_res_input_size=64, norm_pix_loss=norm_pix)
