@@ -31,6 +31,17 @@ if os.environ.get("OCTMAE_SKIP_2GPU_TEST") is None and torch.cuda.device_count()
          "--master-port", "29617", os.path.join(ROOT, "tests", "dp_worker.py")],
         cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
 
+# ---- 2 ranks on ONE GPU, exchange over gloo (every box): the world-size-2 run of the GPU training path -----------------------
+_CHILD_GLOO = None
+_CHILD_GLOO_OUT = None
+if os.environ.get("OCTMAE_SKIP_2RANK_GLOO_TEST") is None and torch.cuda.device_count() >= 1:
+    _CHILD_GLOO_OUT = tempfile.mkdtemp(prefix="octmae_dp_gloo_")
+    env = dict(os.environ, OCTMAE_DP_OUT=_CHILD_GLOO_OUT, OCTMAE_DP_BACKEND="gloo")
+    _CHILD_GLOO = subprocess.Popen(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", "29619", os.path.join(ROOT, "tests", "dp_worker.py")],
+        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+
 if torch.cuda.is_available():
     from octcubem_amd import comm as ocomm, models_mae, misc, optim as foptim
     from octcubem_amd.parallel import FlatGradReducer
@@ -176,3 +187,21 @@ def test_two_rank_gradients_equal_the_mean_of_the_local_ones():
     assert res["params_equal_after_broadcast"]
     assert res["max_rel_err"] <= 1e-5, res
     assert res["ranks_agree"]
+
+
+@pytest.mark.skipif(_CHILD_GLOO is None, reason="needs a GPU")
+def test_two_ranks_on_one_gpu_gradients_equal_the_mean_of_the_local_ones():
+    """World size 2 ON HARDWARE with the box's one GPU: two processes share it, each runs the HIP training path on its own
+    volumes, FlatGradReducer exchanges the gradient arena chunk by chunk from inside backward (torch.distributed gloo group on
+    the device tensors: RCCL refuses two ranks on one device).  Three steps -- the learning step, then two with the frozen
+    readiness layout (cold chunks exchanged at begin_backward) -- and after each the exchanged arena must equal the mean of the
+    two ranks' local gradients, recomputed by every rank alone; different initial weights per rank check the broadcast."""
+    out, _ = _CHILD_GLOO.communicate(timeout=900)
+    assert _CHILD_GLOO.returncode == 0, out.decode(errors="replace")[-4000:]
+    res = json.load(open(os.path.join(_CHILD_GLOO_OUT, "result.json")))
+    assert res["world"] == 2 and res["backend"].startswith("gloo")
+    assert res["params_equal_after_broadcast"]
+    assert res["max_rel_err"] <= 1e-5, res
+    assert res["ranks_agree"]
+    assert res["cold"] == ["high_res_patch_embed.proj.bias", "high_res_patch_embed.proj.weight"], res["cold"]
+    assert res["reducer"]["launched_in_backward"] > 0
