@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--clip-grad", type=float, default=None)
     ap.add_argument("--force-reducer", action="store_true", help="single rank: still create the RCCL group and run the reducer")
     ap.add_argument("--torch-nccl", action="store_true", help="exchange through torch.distributed's NCCL group instead of octmae_comm_*")
+    ap.add_argument("--gloo-one-gpu", action="store_true",
+                    help="diagnostic: every rank on GPU 0, exchange over gloo -- exercises the multi-rank control flow of this script on "
+                         "a one-GPU box (RCCL refuses two ranks on one device); the number it prints is not a benchmark")
     args = ap.parse_args()
 
     # ONE line on stdout: RCCL prints a version banner to stdout when a communicator is created (NCCL_DEBUG=VERSION/WARN), and
@@ -135,7 +138,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.gloo_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
@@ -153,10 +156,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         # torch.distributed is the control plane only (its store carries the RCCL unique id): no device_id, so its own NCCL
         # communicator is created lazily -- i.e. never, unless the native communicator cannot be built.
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend="gloo" if args.gloo_one_gpu else "nccl", rank=rank, world_size=world)
         try:
-            if args.torch_nccl:
-                raise RuntimeError("--torch-nccl")
+            if args.torch_nccl or args.gloo_one_gpu:
+                raise RuntimeError("--gloo-one-gpu" if args.gloo_one_gpu else "--torch-nccl")
             comm = ocomm.NativeComm.from_store(dist.distributed_c10d._get_default_store(), rank, world, local_rank)
             ocomm.set_default(comm)
             comm_kind = "octmae_comm (RCCL behind the C ABI)"
@@ -164,7 +167,7 @@ def main():
             print(f"[bench] rank {rank}: native RCCL communicator unavailable ({e}); using torch.distributed's", file=sys.stderr,
                   flush=True)
             comm = None
-            comm_kind = f"torch.distributed nccl (native communicator failed: {e})"
+            comm_kind = f"torch.distributed {'gloo' if args.gloo_one_gpu else 'nccl'} (native communicator not used: {e})"
 
     assert args.global_batch % world == 0
     per_rank = args.global_batch // world
@@ -202,7 +205,7 @@ def main():
         if comm is not None:
             return comm.all_reduce_scalar(1.0 if failed else 0.0, ocomm.MAX) > 0.0
         if use_dist:
-            t = torch.tensor([1.0 if failed else 0.0], device=dev)
+            t = torch.tensor([1.0 if failed else 0.0], device="cpu" if args.gloo_one_gpu else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item()) > 0.0
         return failed
@@ -264,7 +267,7 @@ def main():
     if comm is not None:
         dt = comm.all_reduce_scalar(dt, ocomm.MAX)
     elif use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.gloo_one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_value = float(loss)
