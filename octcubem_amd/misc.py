@@ -131,27 +131,37 @@ def get_grad_norm_(parameters, norm_type: float = 2.0) -> torch.Tensor:
 
 
 class NativeScalerWithGradNormCount:
-    """``loss_scaler(loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True) -> norm``.
+    """``loss_scaler(loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True) -> norm``
+    (custom_util/misc.py:308-353).
 
-    bf16 needs no loss scaling, so ``fp32=True``/bf16 runs keep scale == 1; the fp16 GradScaler state machine of
-    the reference is preserved for checkpoint compatibility (state_dict key "amp_scaler").  Gradient clipping is
-    applied inside the fused AdamW kernel as a device-side coefficient (no host synchronisation).
+    The compute type here is bf16, which needs no loss scaling: by default the scale is identically 1 whatever ``fp32`` says.
+    ``dynamic_loss_scale=True`` (with ``fp32=False``) runs the reference's fp16 machinery -- torch.cuda.amp.GradScaler as
+    custom_util/misc.py:311-344 drives it -- for drop-in behaviour and checkpoint round trips (state_dict key "amp_scaler"):
+    the loss is multiplied by the scale before backward; gradients are un-scaled inside the fused AdamW kernel (one device-side
+    coefficient together with the clip factor, no extra pass); a non-finite gradient norm SKIPS the optimizer step and halves the
+    scale (one host read of the norm per step, as GradScaler.step has); ``growth_interval`` consecutive good steps double it.
     A ``reducer`` (parallel.FlatGradReducer) -- if given -- is flushed before the norm is taken, which is where the
     data-parallel all-reduce that overlapped with backward is waited for.
     """
     state_dict_key = "amp_scaler"
 
-    def __init__(self, fp32=False, reducer=None):
-        self.enabled = False          # bf16 / fp32 path: scale is identically 1
-        self._scale = 1.0
+    def __init__(self, fp32=False, reducer=None, dynamic_loss_scale=False, init_scale=65536.0, growth_factor=2.0,
+                 backoff_factor=0.5, growth_interval=2000):
+        self.enabled = bool(dynamic_loss_scale) and not fp32
+        self._scale = float(init_scale) if self.enabled else 1.0
+        self._growth_factor, self._backoff_factor, self._growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
         self._growth_tracker = 0
         self.reducer = reducer
+        self.last_step_skipped = False
+
+    def get_scale(self):
+        return self._scale
 
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True,
                  cancel_last_layer_grad=False, named_parameters=None, epoch_and_freeze_last_layer_gradient_epoch=None):
         if self.reducer is not None:
             self.reducer.begin_backward(sync=update_grad)
-        loss.backward(create_graph=create_graph)
+        (loss * self._scale if self.enabled else loss).backward(create_graph=create_graph)
         if not update_grad:
             return None
         if self.reducer is not None:
@@ -159,22 +169,55 @@ class NativeScalerWithGradNormCount:
         params = list(parameters) if parameters is not None else [p for g in optimizer.param_groups for p in g["params"]]
         if clip_grad is not None:
             assert parameters is not None
-        norm, coef = _optim.grad_norm_and_coef(params, clip_grad, _norm_cache)
-        if isinstance(optimizer, _optim.FusedAdamW):
-            optimizer.set_grad_scale(coef if clip_grad is not None else None)
-        elif clip_grad is not None:
-            for p in params:
-                if p.grad is not None:
-                    p.grad.mul_(coef)
-        optimizer.step()
+        if not self.enabled:
+            norm, coef = _optim.grad_norm_and_coef(params, clip_grad, _norm_cache)
+            if isinstance(optimizer, _optim.FusedAdamW):
+                optimizer.set_grad_scale(coef if clip_grad is not None else None)
+            elif clip_grad is not None:
+                for p in params:
+                    if p.grad is not None:
+                        p.grad.mul_(coef)
+            optimizer.step()
+            return norm
+        # ---- fp16-style dynamic loss scale (GradScaler.unscale_ / step / update)
+        scaled_norm, _ = _optim.grad_norm_and_coef(params, None, _norm_cache)
+        norm = scaled_norm / self._scale
+        found_inf = not bool(torch.isfinite(norm).item())
+        self.last_step_skipped = found_inf
+        if not found_inf:
+            inv = 1.0 / self._scale
+            if clip_grad is not None:
+                coef = torch.clamp(float(clip_grad) / (norm + 1e-6), max=1.0) * inv      # clip_grad_norm_'s coefficient x 1 / scale
+            else:
+                coef = torch.full((), inv, dtype=torch.float32, device=norm.device)
+            if isinstance(optimizer, _optim.FusedAdamW):
+                optimizer.set_grad_scale(coef)
+            else:
+                for p in params:
+                    if p.grad is not None:
+                        p.grad.mul_(coef)
+            optimizer.step()
+            if isinstance(optimizer, _optim.FusedAdamW):
+                optimizer.set_grad_scale(None)
+            self._growth_tracker += 1
+            if self._growth_tracker >= self._growth_interval:
+                self._scale *= self._growth_factor
+                self._growth_tracker = 0
+        else:
+            self._scale *= self._backoff_factor
+            self._growth_tracker = 0
         return norm
 
     def state_dict(self):
-        return {"scale": self._scale, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000,
-                "_growth_tracker": self._growth_tracker}
+        return {"scale": self._scale, "growth_factor": self._growth_factor, "backoff_factor": self._backoff_factor,
+                "growth_interval": self._growth_interval, "_growth_tracker": self._growth_tracker}
 
     def load_state_dict(self, state_dict):
-        self._scale = float(state_dict.get("scale", 1.0)) if self.enabled else 1.0
+        if self.enabled:
+            self._scale = float(state_dict.get("scale", self._scale))
+            self._growth_factor = float(state_dict.get("growth_factor", self._growth_factor))
+            self._backoff_factor = float(state_dict.get("backoff_factor", self._backoff_factor))
+            self._growth_interval = int(state_dict.get("growth_interval", self._growth_interval))
         self._growth_tracker = int(state_dict.get("_growth_tracker", 0))
 
 

@@ -493,3 +493,44 @@ def test_use_flash_attn_model_has_flash_keys_and_flash_semantics():
         if float(gr.norm()) < 1e-6 * total or k.endswith("attn.k.bias"):
             continue
         assert rel(mine[k], gr) <= 5e-2, (k, rel(mine[k], gr))
+
+
+def test_dynamic_loss_scale_state_machine(golden_dir):
+    """NativeScalerWithGradNormCount(fp32=False, dynamic_loss_scale=True): the reference's fp16 GradScaler behaviour
+    (custom_util/misc.py:311-344) on top of the bf16 path -- a power-of-two scale changes nothing (same update as the unscaled
+    step, bit for bit: every product scales exactly), a non-finite gradient skips the step and halves the scale, growth_interval
+    good steps double it, and the state round-trips through the "amp_scaler" checkpoint entry."""
+    z, cfg, P = small(golden_dir)
+    imgs, noise = torch.from_numpy(z["imgs"]).to(DEV), torch.from_numpy(z["noise"]).to(DEV)
+
+    def one(scaler, m, opt, loss_mul=1.0):
+        opt.zero_grad()
+        loss, _, _ = m(imgs, mask_ratio=0.75, noise=noise)
+        return scaler(loss * loss_mul, opt, parameters=list(m.parameters()), clip_grad=1.0)
+
+    ma, mb = build(cfg, P), build(cfg, P)
+    oa = foptim.FusedAdamW(misc.add_weight_decay(ma, 0.05), lr=1e-3, betas=(0.9, 0.95))
+    ob = foptim.FusedAdamW(misc.add_weight_decay(mb, 0.05), lr=1e-3, betas=(0.9, 0.95))
+    sa = misc.NativeScalerWithGradNormCount(fp32=True)
+    sb = misc.NativeScalerWithGradNormCount(fp32=False, dynamic_loss_scale=True, init_scale=65536.0, growth_interval=2)
+    assert sb.get_scale() == 65536.0 and sa.get_scale() == 1.0
+    na, nb = one(sa, ma, oa), one(sb, mb, ob)
+    torch.cuda.synchronize()
+    assert abs(float(na) - float(nb)) <= 1e-6 * float(na)
+    for (k, pa), (_, pb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        assert torch.equal(pa, pb), k                               # the scaled step IS the unscaled step
+    before = {k: v.clone() for k, v in mb.state_dict().items()}
+    nn_ = one(sb, mb, ob, loss_mul=float("inf"))                    # non-finite gradients: skipped, scale halves, tracker resets
+    assert not torch.isfinite(nn_) and sb.last_step_skipped and sb.get_scale() == 32768.0
+    for k, v in mb.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    one(sb, mb, ob); assert sb.get_scale() == 32768.0 and not sb.last_step_skipped
+    one(sb, mb, ob); assert sb.get_scale() == 65536.0               # growth_interval = 2 good steps
+    st = sb.state_dict()
+    assert st == {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2, "_growth_tracker": 0}
+    sc = misc.NativeScalerWithGradNormCount(fp32=False, dynamic_loss_scale=True)
+    sc.load_state_dict({"scale": 1024.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 7})
+    assert sc.get_scale() == 1024.0 and sc.state_dict()["_growth_tracker"] == 7
+    sd = misc.NativeScalerWithGradNormCount(fp32=True)
+    sd.load_state_dict(st)                                          # a bf16 / fp32 run accepts the entry and keeps scale 1
+    assert sd.get_scale() == 1.0
