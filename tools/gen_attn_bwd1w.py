@@ -25,6 +25,7 @@ import os
 import sys
 
 IMG_BUF = 512 * 64        # bytes of one dS image: [512 keys][32 queries] bf16
+IMG_BUF64 = 256 * 64      # head_dim 64: [256 keys][32 queries]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "octcubem_amd", "csrc", "attn_bwd1w_body.inc")
@@ -41,6 +42,52 @@ class Op:
     @property
     def cost(self):
         return COST[self.kind]
+
+
+def merge(mf, F, need, bundles, issued_m):
+    """Deal the fillers F = [(Op, not-before-MFMA-tag or None)] (list order = dependency order; blocked ones are skipped, not
+    waited for) to the MFMA slots mf, balancing the bundles' issue cost; `need`: MFMA tag -> filler tags that must precede it."""
+    pending = list(F)
+    done_f = set()
+
+    def take(idx):
+        op, _ = pending.pop(idx)
+        done_f.add(op.tag)
+        return op
+
+    def cost_of(op):
+        return op.cost * (2 if op.code.count("lds_tr_ld") == 2 else 1)
+
+    for mi, m in enumerate(mf):
+        pre = []
+        for nt in need.get(m.tag, []):      # fillers this MFMA needs go into the previous bundle, with everything ahead of them
+            while nt not in done_f:
+                idx = next((k for k, (op, after) in enumerate(pending) if after is None or after in issued_m), None)
+                if idx is None:
+                    raise RuntimeError(f"deadlock: {m.tag} needs {nt}")
+                pre.append(take(idx))
+        if pre:
+            if bundles:
+                bundles[-1][1].extend(pre)
+            else:
+                bundles.append((None, pre))
+        issued_m.add(m.tag)
+        fill = []
+        c = 0.0
+        remaining_m = len(mf) - mi - 1
+        tgt = sum(cost_of(op) for op, _ in pending) / (remaining_m + 1)
+        while True:
+            idx = next((k for k, (op, after) in enumerate(pending) if after is None or after in issued_m), None)
+            if idx is None:
+                break
+            oc = cost_of(pending[idx][0])
+            if c + oc / 2 > tgt and fill:
+                break
+            fill.append(take(idx))
+            c += oc
+        bundles.append((m, fill))
+    if pending:
+        raise RuntimeError("fillers left over: " + " ".join(op.tag for op, _ in pending))
 
 
 def sub_step(s):
@@ -158,49 +205,121 @@ def sub_step(s):
         }
         for j in dj:
             need[f"MD({j})"] = [f"RD{j}h"] if g == 0 else []
-        pending = list(F)                   # fillers not yet placed, in list order; blocked ones are skipped, not waited for
-        done_f = set()
-
-        def take(idx):
-            op, _ = pending.pop(idx)
-            done_f.add(op.tag)
-            return op
-
-        def cost_of(op):
-            return op.cost * (2 if op.code.count("lds_tr_ld") == 2 else 1)
-
-        for mi, m in enumerate(mf):
-            pre = []
-            for nt in need.get(m.tag, []):      # fillers this MFMA needs go into the previous bundle, with everything ahead of them
-                while nt not in done_f:
-                    idx = next((k for k, (op, after) in enumerate(pending) if after is None or after in issued_m), None)
-                    if idx is None:
-                        raise RuntimeError(f"deadlock: {m.tag} needs {nt}")
-                    pre.append(take(idx))
-            if pre:
-                if bundles:
-                    bundles[-1][1].extend(pre)
-                else:
-                    bundles.append((None, pre))
-            issued_m.add(m.tag)
-            fill = []
-            c = 0.0
-            remaining_m = len(mf) - mi - 1
-            tgt = sum(cost_of(op) for op, _ in pending) / (remaining_m + 1)
-            while True:
-                idx = next((k for k, (op, after) in enumerate(pending) if after is None or after in issued_m), None)
-                if idx is None:
-                    break
-                oc = cost_of(pending[idx][0])
-                if c + oc / 2 > tgt and fill:
-                    break
-                fill.append(take(idx))
-                c += oc
-            bundles.append((m, fill))
-        if pending:
-            raise RuntimeError("fillers left over: " + " ".join(op.tag for op, _ in pending))
+        merge(mf, F, need, bundles, issued_m)
     return bundles
 
+
+
+def sub_step64(s):
+    """head_dim 64: a wave owns 64 keys (two 32-key groups) of a 256-key block; S / dP take 4 k-steps of 16 head dims, dV^T / dK^T
+    two 32-wide head-dim blocks each; the wave's part of dQ^T[64][32] is head-dim tile `wid` (16 dims) of BOTH 16-query tiles over
+    all 256 keys: 8 k-steps x 2 tiles of 16x16x32 MFMAs sharing their K^T fragments.  Same pipeline as head_dim 32 with two
+    group-steps per sub-step.  Register economy (one set of row constants / row fragments / first-half transposed fragments,
+    reloaded as soon as their last reader has been issued; only the second-half transposed fragments, which the C1 MFMAs of the
+    next group-step still read, alternate with the sub-step)."""
+    cur, nxt = ("a", "b") if s == 0 else ("b", "a")
+    bundles = []
+    issued_m = set()
+    dqn = "dqA" if s == 0 else "dqB"
+    dqo = "dqB" if s == 0 else "dqA"
+    rb = ((s + 1) % 2) * IMG_BUF64
+    wb = s * IMG_BUF64
+    for g in range(2):
+        X, Y = ("A", "B") if g == 0 else ("B", "A")
+        gp, pp = (0, cur) if g == 1 else (1, nxt)          # previous group and the parity of ITS second-half transposed fragments
+        gn = 1 - g
+        sa, dp = f"sa{X}", f"dp{X}"
+        mf = [Op("mfma", f"MFMA_ACC(dv{gp}0, oT1{pp}0, pf1);", f"CV1a({gp})"), Op("mfma", f"MFMA_ACC(dv{gp}1, oT1{pp}1, pf1);", f"CV1b({gp})"),
+              Op("mfma", f"MFMA_ACC(dk{gp}0, qT1{pp}0, dsf1);", f"CK1a({gp})"), Op("mfma", f"MFMA_ACC(dk{gp}1, qT1{pp}1, dsf1);", f"CK1b({gp})")]
+        for ks in range(4):
+            mf.append(Op("mfma", f"sa{Y} = mfma32(qrow{ks}, kS[{gn}][{ks}], {'lse_t' if ks == 0 else 'sa' + Y});", f"AS{ks}({gn})"))
+            mf.append(Op("mfma", f"dp{Y} = mfma32(orow{ks}, vS[{gn}][{ks}], {'dlt_t' if ks == 0 else 'dp' + Y});", f"AP{ks}({gn})"))
+        mf += [Op("mfma", f"MFMA_ACC(dv{g}0, oT0d0, pf0);", f"CV0a({g})"), Op("mfma", f"MFMA_ACC(dv{g}1, oT0d1, pf0);", f"CV0b({g})"),
+               Op("mfma", f"MFMA_ACC(dk{g}0, qT0d0, dsf0);", f"CK0a({g})"), Op("mfma", f"MFMA_ACC(dk{g}1, qT0d1, dsf0);", f"CK0b({g})")]
+        for j in range(4 * g, 4 * g + 4):
+            for qt in range(2):
+                c = "zero4" if j == 0 else f"{dqn}{qt}"
+                mf.append(Op("mfma", f"{dqn}{qt} = mfma16(kT[{j}], cat4(bj{j}q{qt}l, bj{j}q{qt}h), {c});", f"MD({j},{qt})"))
+        F = []
+
+        def add(kind, code, after=None, tag=""):
+            F.append((Op(kind, code, tag), after))
+
+        def rd(j):
+            for qt in range(2):
+                x = f" ^ 32u" if qt else ""
+                add("ldsr", f"const bf16x4 bj{j}q{qt}l = lds_tr_ld((a_imglo{x}) + {rb + j * 2048});", tag=f"RD{j}q{qt}l")
+                add("ldsr", f"const bf16x4 bj{j}q{qt}h = lds_tr_ld((a_imghi{x}) + {rb + j * 2048});", tag=f"RD{j}q{qt}h")
+
+        if g == 0:
+            for j in range(4):
+                rd(j)
+            add("vaddr", "const unsigned ao = a_old + s_oldr;", tag="AO")
+            for qt in range(2):
+                add("ldsr", f"const f32x4 rold{qt} = lds_ld<f32x4>(ao + {(s * 2 + qt) * 4096});", tag=f"ROLD{qt}")
+        if g == 1:
+            # second-half transposed fragments of the NEXT sub-step (the other parity: last read by this sub-step's first C1 MFMAs)
+            nx = "1" if s == 0 else "n"
+            add("vaddr", f"const unsigned pl1_ = a_trlo + s_x{nx};", tag="PL1")
+            add("vaddr", f"const unsigned ph1_ = a_trhi + s_x{nx};", tag="PH1")
+            for d in range(2):
+                add("ldsr", f"qT1{nxt}{d} = cat4(lds_tr_ld((pl1_ ^ {64 * d}u) + {16 * 128}), lds_tr_ld((ph1_ ^ {64 * d}u) + {16 * 128}));",
+                    after="CK1b(0)", tag=f"LT1q{d}")
+                add("ldsr", f"oT1{nxt}{d} = cat4(lds_tr_ld((pl1_ ^ {64 * d}u) + {16 * 128} + (OR_ - QR)), lds_tr_ld((ph1_ ^ {64 * d}u) + {16 * 128} + (OR_ - QR)));",
+                    after="CK1b(0)", tag=f"LT1o{d}")
+        for half in range(2):
+            e0 = 8 * half
+            pf, dsf = f"pf{half}", f"dsf{half}"
+            if half == 1 and g == 0:
+                # next sub-step's row constants and row fragments: A(1), issued in this group-step, was the last reader of the old ones
+                nx = "1" if s == 0 else "n"
+                add("vaddr", f"const unsigned pc_ = a_const + s_pc{nx};", after="AP3(1)", tag="PC")
+                add("vaddr", f"const unsigned pr_ = a_row + s_x{nx};", after="AP3(1)", tag="PR")
+                for G in range(4):
+                    add("ldsr", f"{{ const f32x4 c_ = lds_ld<f32x4>(pc_ + {32 * G}); lse_t[{4 * G}] = c_[0]; lse_t[{4 * G + 1}] = c_[1]; "
+                                f"lse_t[{4 * G + 2}] = c_[2]; lse_t[{4 * G + 3}] = c_[3]; }}", after="AP3(1)", tag=f"LCa{G}")
+                    add("ldsr", f"{{ const f32x4 c_ = lds_ld<f32x4>(pc_ + {256 + 32 * G}); dlt_t[{4 * G}] = c_[0]; dlt_t[{4 * G + 1}] = c_[1]; "
+                                f"dlt_t[{4 * G + 2}] = c_[2]; dlt_t[{4 * G + 3}] = c_[3]; }}", after="AP3(1)", tag=f"LCd{G}")
+                for ks in range(4):
+                    add("ldsr", f"qrow{ks} = lds_ld<bf16x8>(pr_ ^ {32 * ks}u);", after="AP3(1)", tag=f"LQ{ks}")
+                    add("ldsr", f"orow{ks} = lds_ld<bf16x8>((pr_ ^ {32 * ks}u) + (OR_ - QR));", after="AP3(1)", tag=f"LO{ks}")
+            for e in range(e0, e0 + 8):
+                add("exp", f"{sa}[{e}] = fast_exp2({sa}[{e}]);", tag=f"E{e}")
+            for e in range(e0, e0 + 8):
+                add("mul", f"{dp}[{e}] = {sa}[{e}] * {dp}[{e}];", tag=f"MU{e}")
+            for i in range(4):
+                add("cvt", f"{pf}[{i}] = pack2bf({sa}[{e0 + 2 * i}], {sa}[{e0 + 2 * i + 1}]);", tag=f"CP{4 * half + i}")
+            for i in range(4):
+                add("cvt", f"{dsf}[{i}] = pack2bf({dp}[{e0 + 2 * i}], {dp}[{e0 + 2 * i + 1}]);", tag=f"CD{4 * half + i}")
+            add("ldsw8", f"lds_st<u32x2>((a_imgw ^ {32 * half}u) + {wb + g * 32 * 64}, u32x2{{{dsf}[0], {dsf}[1]}});", tag=f"WR{half}0")
+            add("ldsw8", f"lds_st<u32x2>((a_imgw ^ {32 * half + 16}u) + {wb + g * 32 * 64}, u32x2{{{dsf}[2], {dsf}[3]}});", tag=f"WR{half}1")
+            if half == 0 and g == 0:
+                for qt in range(2):
+                    add("add", f"f32x4 rv{qt}; rv{qt}[0] = {dqo}{qt}[0] + rold{qt}[0]; rv{qt}[1] = {dqo}{qt}[1] + rold{qt}[1]; "
+                               f"rv{qt}[2] = {dqo}{qt}[2] + rold{qt}[2]; rv{qt}[3] = {dqo}{qt}[3] + rold{qt}[3];", tag=f"RA{qt}")
+                add("vaddr", f"const unsigned rvo = wsoff + s_redoff{s};", tag="RVO")
+                add("store", "__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rv0), rsWs, rvo, 0, 0);", tag="RST0")
+                add("store", "__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rv1), rsWs, rvo + 4096u, 0, 0);", tag="RST1")
+            if half == 0 and g == 1 and s == 0:
+                add("dma", "issue_tile();", tag="DMA")
+            if half == 1 and g == 0:
+                for j in range(4, 8):
+                    rd(j)
+        if g == 1:
+            # first-half transposed fragments of the next sub-step: C0(1) of this one was their last reader
+            nx = "1" if s == 0 else "n"
+            add("vaddr", f"const unsigned pl0_ = a_trlo + s_x{nx};", after="CK0b(1)", tag="PL0")
+            add("vaddr", f"const unsigned ph0_ = a_trhi + s_x{nx};", after="CK0b(1)", tag="PH0")
+            for d in range(2):
+                add("ldsr", f"qT0d{d} = cat4(lds_tr_ld(pl0_ ^ {64 * d}u), lds_tr_ld(ph0_ ^ {64 * d}u));", after="CK0b(1)", tag=f"LT0q{d}")
+                add("ldsr", f"oT0d{d} = cat4(lds_tr_ld((pl0_ ^ {64 * d}u) + (OR_ - QR)), lds_tr_ld((ph0_ ^ {64 * d}u) + (OR_ - QR)));",
+                    after="CK0b(1)", tag=f"LT0o{d}")
+        need = {f"CV0a({g})": ["CP3"], f"CK0a({g})": ["CD3"]}
+        if g == 0:
+            for j in range(4):
+                need[f"MD({j},0)"] = [f"RD{j}q1h"]
+        merge(mf, F, need, bundles, issued_m)
+    return bundles
 
 def guard(o):
     """Timing-only ablation switches (-DABL_...: results are wrong, the instruction stream is otherwise unchanged)."""
@@ -216,16 +335,16 @@ def guard(o):
     return f"\n#ifndef {g}\n  {o.code}\n#endif\n "
 
 
-def emit():
+def emit(hd=32):
     out = ["// GENERATED by tools/gen_attn_bwd1w.py -- do not edit; the bundle order is the instruction order (see the generator's header)."]
     report = []
     for s in range(2):
         out.append(f"// ======================== sub-step {s} of the tile ========================")
         out.append("{")
-        bl = sub_step(s)
+        bl = sub_step(s) if hd == 32 else sub_step64(s)
         nst = 0
         for bi, (m, fill) in enumerate(bl):
-            if m and (m.tag.startswith("CV1") or m.tag.startswith("CV0")):
+            if m and (m.tag.startswith(("CV1(", "CV0(", "CV1a", "CV0a"))):
                 out.append(f"  STAMP({nst});")
                 nst += 1
             cost = (m.cost if m else 0) + sum(o.cost for o in fill)
@@ -252,12 +371,19 @@ def emit():
 
 
 if __name__ == "__main__":
-    text, report = emit()
+    text, report = emit(32)
     with open(OUT, "w") as f:
         f.write(text)
     tot = sum(r[4] for r in report)
     nm = sum(1 for r in report if r[2] != "-")
     print(f"wrote {OUT}: {len(report)} bundles, {nm} MFMAs per tile, issue estimate {tot} cycles per tile")
+    text64, report64 = emit(64)
+    with open(OUT.replace("_body.inc", "_body_hd64.inc"), "w") as f:
+        f.write(text64)
+    print(f"wrote the head_dim-64 body: {len(report64)} bundles, issue estimate {sum(r[4] for r in report64)} cycles per tile")
+    if "--report64" in sys.argv:
+        report = report64
+        sys.argv.append("--report")
     if "--report" in sys.argv:
         for s, bi, m, fl, cost in report:
             print(f"s{s} b{bi:02d} {m:10s} {cost:5.0f}  " + " ".join(fl))
