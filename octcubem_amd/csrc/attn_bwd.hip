@@ -875,7 +875,11 @@ __global__ __launch_bounds__(256) void attn_bwd_tail1_kernel(const bf16_t* __res
 // one wave per SIMD, head_dim 32 (attn_bwd1w.hip)
 int launch_attn_bwd_fused1w(const bf16_t* qkv, const bf16_t* dout, const float* rowc, float* dq_ws, bf16_t* dqkv, int B, int N, int NPAD,
                             int H, int nkb, float scale, hipStream_t st);
+// one wave per SIMD, head_dim 64 (attn_bwd1w64.hip)
+int launch_attn_bwd_fused1w64(const bf16_t* qkv, const bf16_t* dout, const float* rowc, float* dq_ws, bf16_t* dqkv, int B, int N, int NPAD,
+                              int H, int nkb, float scale, hipStream_t st);
 std::atomic<int> g_attn_bwd_hd32_form{1};
+std::atomic<int> g_attn_bwd_hd64_form{1};
 
 template <int HD>
 static int run_fused(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, const float* lse, float* ws, bf16_t* dqkv, int B, int N,
@@ -895,6 +899,8 @@ static int run_fused(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, con
   const int nkb = N / C::KB;
   if (nkb > 0 && HD == 32 && g_attn_bwd_hd32_form.load(std::memory_order_relaxed) == 1) {
     if (int rc = launch_attn_bwd_fused1w(qkv, dout, rowc, dq_ws, dqkv, B, N, NPAD, H, nkb, scale, st)) return rc;
+  } else if (nkb > 0 && HD == 64 && g_attn_bwd_hd64_form.load(std::memory_order_relaxed) == 1) {
+    if (int rc = launch_attn_bwd_fused1w64(qkv, dout, rowc, dq_ws, dqkv, B, N, NPAD, H, nkb, scale, st)) return rc;
   } else if (nkb > 0) {
     static DynLdsOnce once;
     if (int rc = once.ensure(reinterpret_cast<const void*>(attn_bwd_fused_kernel<HD>), C::LDS)) return rc;
@@ -929,6 +935,7 @@ extern "C" int octmae_debug_bwd_stamps(void* host, int nbytes) {
 extern "C" int octmae_set_option(const char* key, int value) {
   if (key == nullptr) return -1;
   if (__builtin_strcmp(key, "attn_bwd_hd32_form") == 0) return g_attn_bwd_hd32_form.exchange(value ? 1 : 0);
+  if (__builtin_strcmp(key, "attn_bwd_hd64_form") == 0) return g_attn_bwd_hd64_form.exchange(value ? 1 : 0);
   return -1;
 }
 

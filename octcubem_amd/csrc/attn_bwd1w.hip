@@ -14,7 +14,7 @@
 //     tile LATER, behind the single workgroup barrier of the tile, so no wave ever waits for another's arithmetic;
 //   * Q / dO / row-constant tiles arrive by LDS-DMA through a 3-deep ring two tiles ahead, retired by counted vmcnt.
 // Reference op: backward of softmax((q k^T) scale) v, Pre-training/custom_util/video_vit.py:130-134 under autograd.
-#include "attn_tile.hpp"
+#include "attn_bwd1w.hpp"
 #include "../../include/octmae.h"
 
 namespace octmae {
@@ -38,52 +38,7 @@ constexpr int STG = IMG;                                // K rows of the block [
 static_assert(LDS <= 160 * 1024, "LDS budget");
 static_assert((CR % 128) == 0 && (IMG % 128) == 0 && (OLD % 128) == 0, "XOR chunk selectors act on address bits 0..6");
 
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-
-template <int CNT>
-__device__ __forceinline__ void wait_vm() {
-  static_assert(CNT >= 0 && CNT < 64, "vmcnt is 6 bits");
-  __builtin_amdgcn_s_waitcnt((CNT & 15) | ((CNT >> 4) << 14) | (7 << 4) | (15 << 8));
-}
-__device__ __forceinline__ void lds_dma16(unsigned m0v, unsigned voff, i32x4_t rsrc) {
-  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc) : "memory", "m0");
-}
-__device__ __forceinline__ void lds_dma4(unsigned m0v, unsigned voff, i32x4_t rsrc) {
-  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc) : "memory", "m0");
-}
-__device__ __forceinline__ i32x4_t make_rsrc(const void* base, unsigned bytes) {
-  const unsigned long long a = (unsigned long long)base;
-  i32x4_t r = {(int)(unsigned)a, (int)(unsigned)(a >> 32), (int)bytes, 0x00020000};
-  r[0] = __builtin_amdgcn_readfirstlane(r[0]);
-  r[1] = __builtin_amdgcn_readfirstlane(r[1]);
-  r[2] = __builtin_amdgcn_readfirstlane(r[2]);
-  r[3] = __builtin_amdgcn_readfirstlane(r[3]);
-  return r;
-}
-// 8-byte chunk c8 (4 bf16) of row `row` of a [rows][64 B] image: ds_write_b64 by 16 consecutive rows and the transposed reads of
-// 4 consecutive rows (one aligned 256-byte line) are both conflict-free for any within-row permutation that separates the 8
-// even (odd) rows of a 16-row run
-__device__ __forceinline__ int img_off(int row, int c8) { return row * 64 + ((c8 ^ ((row >> 1) & 7)) << 3); }
-
-// dV^T / dK^T accumulate in the ACCUMULATOR half of the register file (128 of this wave's 512 registers), where only MFMAs touch
-// them; the MFMAs whose results the vector ALU consumes (S, dP, dQ^T) are the compiler's builtins with VGPR destinations
-// (-mllvm -amdgpu-mfma-vgpr-form, see the Makefile).  One function cannot have both forms from builtins, hence the asm.  Hazards
-// (the compiler pads nothing inside asm): the A / B operands are written by v_cvt_pk at least two instructions earlier (the
-// generator pins their last producer), the accumulate chain needs no wait states, and the read-out after the loop sits behind
-// explicit s_nops.
-#define MFMA_ACC(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
-// end of a sub-step: this wave's dS image rows are written (LDS operations complete in order: at most the N reads issued after
-// the last image write may still be pending), then the workgroup barrier
-#ifdef ABL_NO_BARRIER
-#define SUBSTEP_END(N) __builtin_amdgcn_s_waitcnt(0xC07F | 0)
-#else
-#define SUBSTEP_END(N)                                            \
-  do {                                                            \
-    __builtin_amdgcn_s_waitcnt(0xC07F | ((N) << 8));              \
-    __builtin_amdgcn_s_barrier();                                 \
-  } while (0)
-#endif
+using namespace bwd1w_util;
 
 // ---- diagnostic build (-DBWD1W_STAMP, make stamp): s_memtime at the start and the middle of every group-step, before the
 // end-of-sub-step wait and behind the barrier; per-wave sums of the 10 intervals of each sub-step (tools/attn_bwd1w_stamps.py).
@@ -125,6 +80,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
   const bf16_t* vb_ = qb + (size_t)2 * H * HD;
   const bf16_t* dob = dout + (size_t)b * N * os + (size_t)head * HD;
   const float sc2 = scale * LOG2E;
+  const bool half_drain = ((N - 1) & 63) < 32;    // the last tile's rows 32 .. 63 are all >= N
   const int ntiles = (N + 63) / 64;               // NPAD = 64 (ntiles + 1): one all-padding tile of row constants behind the last
 
   // ---- LDS-DMA plan: a tile is 4 Q pieces + 4 dO pieces of 1 KiB; waves 0, 1 bring Q, waves 2, 3 dO (2 pieces each) and every
@@ -193,6 +149,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
   for (int kb = 0; kb < nkb; ++kb) {
     const int key0 = kb * KB;
     const unsigned oldbase = kb > 0 ? 0u : DROP;
+    // ---- ring prologue: tiles 0 .. 2, workspace values of tile 0 -- requested first, their latency runs beside the K staging.
+    // (The ring, the constants and the workspace-value buffers are not the image region; LDS-DMA writes of one wave land in
+    // issue order, so the surplus tiles the previous block's loop left in flight need no drain.)
+    issue(0, 0, 0);
+    issue(1, 1, 1);
+    issue(2, 2, 2);
+    oldreq(0, 0, oldbase);
     // ---- stage this block's K rows for the transposed reads of the loop-invariant K^T fragments
     {
 #pragma unroll
@@ -229,14 +192,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
     __syncthreads();                              // every wave has its K^T fragments: the image region is free
 
     // (every load the compiler tracks has returned: without this it carries "loads pending" into the tile loop and waits there
-    // with a vmcnt that also drains the hand-counted LDS-DMA ring)
+    // with a vmcnt that also drains the hand-counted LDS-DMA ring; the ring prologue, requested before the K staging, is
+    // complete with them)
     wait_vm<0>();
-    // ---- ring prologue: tiles 0 .. 2, workspace values of tile 0; tiles 0 and 1 complete behind the barrier
-    issue(0, 0, 0);
-    issue(1, 1, 1);
-    issue(2, 2, 2);
-    oldreq(0, 0, oldbase);
-    wait_vm<5>();
     __builtin_amdgcn_s_barrier();
 
     // ---- pipeline prologue: fragments of sub-step (0, 0), S / dP of its first key group; everything the first C1 / D / reduce
@@ -282,21 +240,38 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(st_[9]));
     last_ = (unsigned)st_[9];
 #endif
-    for (int t = 0; t <= ntiles; ++t) {
+    // per-iteration scalars (ring slots, write-out offsets) and the request of tile t + 3 / the workspace values of tile t + 1
+#define BWD1W_TILE_SETUP                                                                                            \
+  const int slot = t & (NB - 1), slotn = (t + 1) & (NB - 1);                                                        \
+  const unsigned s_pc1 = (unsigned)(slot * 512 + 128), s_x1 = (unsigned)(slot * T::BYTES + 32 * T::ROWB);           \
+  const unsigned s_pcn = (unsigned)(slotn * 512), s_xn = (unsigned)(slotn * T::BYTES);                              \
+  const unsigned s_oldr = (unsigned)(((t + 2) % NOLD) * 2 * NW * 1024);                                             \
+  const unsigned s_redoff0 = t > 0 ? (unsigned)(t - 1) * WS_TILE : DROP;                                            \
+  const unsigned s_redoff1 = t > 0 ? (unsigned)(t - 1) * WS_TILE + WS_SUB : DROP;                                   \
+  auto issue_tile = [&]() {                                                                                         \
+    const int tn = t + LA;                                                                                          \
+    issue(tn < ntiles ? tn : tn - ntiles, tn < ntiles ? tn : ntiles, tn & (NB - 1));                                \
+    oldreq(t + 1, (t + 1) % NOLD, oldbase);                                                                         \
+  };
+    // The draining iteration t = ntiles: its sub-step 0 finishes tile ntiles - 1 (dK / dV of its second half, dQ of its second
+    // half summed, its first half written out); its sub-step 1 only writes that second half out -- nothing when those 32 rows are
+    // all >= N (N = 64 m + 1 .. 64 m + 32: the cls token makes the model's lengths 64 m + 1).  Then the loop runs the full
+    // iterations and half an iteration follows as straight-line code: no exit from the middle of the loop body.
+    const int nfull = half_drain ? ntiles : ntiles + 1;
+    for (int t = 0; t < nfull; ++t) {
       if (t > 0) wait_vm<7>();
-      const int slot = t & (NB - 1), slotn = (t + 1) & (NB - 1);
-      const unsigned s_pc1 = (unsigned)(slot * 512 + 128), s_x1 = (unsigned)(slot * T::BYTES + 32 * T::ROWB);
-      const unsigned s_pcn = (unsigned)(slotn * 512), s_xn = (unsigned)(slotn * T::BYTES);
-      const unsigned s_oldr = (unsigned)(((t + 2) % NOLD) * 2 * NW * 1024);
-      const unsigned s_redoff0 = t > 0 ? (unsigned)(t - 1) * WS_TILE : DROP;
-      const unsigned s_redoff1 = t > 0 ? (unsigned)(t - 1) * WS_TILE + WS_SUB : DROP;
-      auto issue_tile = [&]() {
-        const int tn = t + LA;
-        issue(tn < ntiles ? tn : tn - ntiles, tn < ntiles ? tn : ntiles, tn & (NB - 1));
-        oldreq(t + 1, (t + 1) % NOLD, oldbase);
-      };
+      BWD1W_TILE_SETUP
 #include "attn_bwd1w_body.inc"
     }
+    if (half_drain) {
+      const int t = ntiles;
+      wait_vm<7>();
+      BWD1W_TILE_SETUP
+#define BWD1W_ONLY_SUBSTEP0
+#include "attn_bwd1w_body.inc"
+#undef BWD1W_ONLY_SUBSTEP0
+    }
+#undef BWD1W_TILE_SETUP
 #ifdef BWD1W_STAMP
     if (kb == 1 && lane == 0 && blockIdx.x < 512)
       for (int s_ = 0; s_ < 2; ++s_)
@@ -322,11 +297,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
         }
       }
     }
-    // next block: its workspace read-modify-write of a row is done by the same lane as this block's (program order); drain
-    // everything (the surplus tiles of the ring included) before the K staging reuses the partial-tile region
-    wait_vm<0>();
-    __syncthreads();
+    // next block: its workspace read-modify-write of a row is done by the same lane as this block's (program order: a wave's
+    // vector-memory operations complete in issue order), the dK / dV stores above are nobody's input; its K staging overwrites
+    // the image region, which every wave has finished reading behind the loop's last barrier
   }
+  wait_vm<0>();
 }
 
 }  // namespace octmae

@@ -351,13 +351,15 @@ def test_attention_backward_fused_equals_two_kernel_form_closely():
         assert torch.equal(a, a2)                                       # no atomics: bit-reproducible
 
 
-@pytest.mark.parametrize("N,B,H", [(5121, 1, 2), (1536, 2, 3), (1025, 1, 4), (577, 2, 2), (512, 3, 1), (1281, 2, 16)])
-def test_attention_backward_hd32_both_forms(N, B, H):
-    """head_dim 32 has two main kernels behind octmae_attn_bwd_fused (octmae_set_option "attn_bwd_hd32_form"): one wave per SIMD
-    with 4 x 128 keys per workgroup (csrc/attn_bwd1w.hip, the default) and the round-2 kernel with two waves per SIMD and 8 x 64
-    keys (csrc/attn_bwd.hip).  Same rounding points, different summation order of dQ: both against fp64 on the same bf16
-    operands, against each other, and each bit-reproducible."""
-    HD = 32
+@pytest.mark.parametrize("HD,N,B,H", [(32, 5121, 1, 2), (32, 1536, 2, 3), (32, 1025, 1, 4), (32, 577, 2, 2), (32, 512, 3, 1),
+                                      (32, 1281, 2, 16), (64, 1281, 2, 16), (64, 256, 3, 1), (64, 257, 2, 2), (64, 300, 1, 3),
+                                      (64, 777, 2, 2), (64, 2561, 1, 2), (64, 193, 1, 1)])
+def test_attention_backward_both_forms(HD, N, B, H):
+    """Each head_dim has two main kernels behind octmae_attn_bwd_fused (octmae_set_option "attn_bwd_hd32_form" /
+    "attn_bwd_hd64_form"): one wave per SIMD (csrc/attn_bwd1w.hip: 4 x 128 keys per workgroup; csrc/attn_bwd1w64.hip: 4 x 64; the
+    defaults) and the round-2 kernel with two waves per SIMD (csrc/attn_bwd.hip).  Same rounding points, different summation
+    order of dQ: both against fp64 on the same bf16 operands, against each other, and each bit-reproducible."""
+    key = f"attn_bwd_hd{HD}_form"
     g = torch.Generator().manual_seed(N + 7 * H)
     qkv = bf(torch.randn(B * N, 3 * H * HD, generator=g)).to(DEV)
     do = bf(torch.randn(B * N, H * HD, generator=g)).to(DEV)
@@ -367,20 +369,20 @@ def test_attention_backward_hd32_both_forms(N, B, H):
     o_ref.backward(do.double())
     ref = qd.grad.view(B, N, 3, H * HD)
     out = {}
-    prev = ops.set_option("attn_bwd_hd32_form", 1)
+    prev = ops.set_option(key, 1)
     try:
         for form in (1, 0):
-            ops.set_option("attn_bwd_hd32_form", form)
+            ops.set_option(key, form)
             d = ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, HD ** -0.5, fused=True)
             d2 = ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, HD ** -0.5, fused=True)
             assert torch.equal(d, d2), form
             got = d.double().view(B, N, 3, H * HD)
             errs = {name: rel(got[:, :, i], ref[:, :, i]) for i, name in enumerate("qkv")}
-            print(f"attention backward hd32 form {form} N={N}: " + ", ".join(f"d{k} {v:.2e}" for k, v in errs.items()))
+            print(f"attention backward hd{HD} form {form} N={N}: " + ", ".join(f"d{k} {v:.2e}" for k, v in errs.items()))
             assert max(errs.values()) < 1.5e-2, (form, errs)
             out[form] = d
     finally:
-        ops.set_option("attn_bwd_hd32_form", prev)
+        ops.set_option(key, prev)
     a, b_ = out[1].double().view(B, N, 3, H * HD), out[0].double().view(B, N, 3, H * HD)
     assert torch.equal(out[1].view(B, N, 3, H * HD)[:, :, 1:], out[0].view(B, N, 3, H * HD)[:, :, 1:]) or rel(a[:, :, 1:], b_[:, :, 1:]) < 1e-3
     assert rel(a[:, :, 0], b_[:, :, 0]) < 3e-3          # dQ: one bf16 rounding of a differently ordered fp32 sum

@@ -1,6 +1,7 @@
-"""Same-process A/B of the two head_dim-32 main kernels behind octmae_attn_bwd_fused (octmae_set_option "attn_bwd_hd32_form":
-1 = one wave per SIMD, csrc/attn_bwd1w.hip; 0 = two waves per SIMD, csrc/attn_bwd.hip) at the decoder shape; interleaved
-rounds on random data, medians.  B=<micro-batch> (default 32)."""
+"""Same-process A/B of the two main kernels behind octmae_attn_bwd_fused (octmae_set_option "attn_bwd_hd32_form" /
+"attn_bwd_hd64_form": 1 = one wave per SIMD, csrc/attn_bwd1w.hip / attn_bwd1w64.hip; 0 = two waves per SIMD, csrc/attn_bwd.hip)
+at the decoder shape (HD=32, N=5121: default) or the encoder's (HD=64 N=1281); interleaved rounds on random data, medians.
+B=<micro-batch> (default 32)."""
 import os
 import statistics
 import sys
@@ -11,7 +12,9 @@ from octcubem_amd import ops
 
 dev = "cuda"
 B = int(os.environ.get("B", "32"))
-H, N, HD = 16, int(os.environ.get("N", "5121")), 32
+HD = int(os.environ.get("HD", "32"))
+H, N = 16, int(os.environ.get("N", "5121" if HD == 32 else "1281"))
+KEY = f"attn_bwd_hd{HD}_form"
 g = torch.Generator(device=dev).manual_seed(0)
 qkv = torch.randn(B * N, 3 * H * HD, device=dev, generator=g).to(torch.bfloat16)
 do = torch.randn(B * N, H * HD, device=dev, generator=g).to(torch.bfloat16)
@@ -21,7 +24,7 @@ res = {0: [], 1: []}
 outs = {}
 for r in range(int(os.environ.get("ROUNDS", "9"))):
     for form in (1, 0):
-        ops.set_option("attn_bwd_hd32_form", form)
+        ops.set_option(KEY, form)
         torch.cuda.synchronize()
         s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
         s.record()
@@ -29,7 +32,7 @@ for r in range(int(os.environ.get("ROUNDS", "9"))):
         e.record(); torch.cuda.synchronize()
         res[form].append(s.elapsed_time(e))
         outs[form] = d
-ops.set_option("attn_bwd_hd32_form", 1)
+ops.set_option(KEY, 1)
 unit = 2.0 * B * H * N * N * HD
 for form in (1, 0):
     ms = statistics.median(res[form][1:]); mn = min(res[form][1:])

@@ -226,11 +226,11 @@ def sub_step64(s):
     wb = s * IMG_BUF64
     for g in range(2):
         X, Y = ("A", "B") if g == 0 else ("B", "A")
-        gp, pp = (0, cur) if g == 1 else (1, nxt)          # previous group and the parity of ITS second-half transposed fragments
+        gp = 1 - g                                          # previous group (of the previous sub-step when g == 0)
         gn = 1 - g
         sa, dp = f"sa{X}", f"dp{X}"
-        mf = [Op("mfma", f"MFMA_ACC(dv{gp}0, oT1{pp}0, pf1);", f"CV1a({gp})"), Op("mfma", f"MFMA_ACC(dv{gp}1, oT1{pp}1, pf1);", f"CV1b({gp})"),
-              Op("mfma", f"MFMA_ACC(dk{gp}0, qT1{pp}0, dsf1);", f"CK1a({gp})"), Op("mfma", f"MFMA_ACC(dk{gp}1, qT1{pp}1, dsf1);", f"CK1b({gp})")]
+        mf = [Op("mfma", f"MFMA_ACC(dv{gp}0, oT1d0, pf1);", f"CV1a({gp})"), Op("mfma", f"MFMA_ACC(dv{gp}1, oT1d1, pf1);", f"CV1b({gp})"),
+              Op("mfma", f"MFMA_ACC(dk{gp}0, qT1d0, dsf1);", f"CK1a({gp})"), Op("mfma", f"MFMA_ACC(dk{gp}1, qT1d1, dsf1);", f"CK1b({gp})")]
         for ks in range(4):
             mf.append(Op("mfma", f"sa{Y} = mfma32(qrow{ks}, kS[{gn}][{ks}], {'lse_t' if ks == 0 else 'sa' + Y});", f"AS{ks}({gn})"))
             mf.append(Op("mfma", f"dp{Y} = mfma32(orow{ks}, vS[{gn}][{ks}], {'dlt_t' if ks == 0 else 'dp' + Y});", f"AP{ks}({gn})"))
@@ -245,28 +245,28 @@ def sub_step64(s):
         def add(kind, code, after=None, tag=""):
             F.append((Op(kind, code, tag), after))
 
-        def rd(j):
+        def rd(j, after):
             for qt in range(2):
                 x = f" ^ 32u" if qt else ""
-                add("ldsr", f"const bf16x4 bj{j}q{qt}l = lds_tr_ld((a_imglo{x}) + {rb + j * 2048});", tag=f"RD{j}q{qt}l")
-                add("ldsr", f"const bf16x4 bj{j}q{qt}h = lds_tr_ld((a_imghi{x}) + {rb + j * 2048});", tag=f"RD{j}q{qt}h")
+                add("ldsr", f"const bf16x4 bj{j}q{qt}l = lds_tr_ld((a_imglo{x}) + {rb + j * 2048});", after=after, tag=f"RD{j}q{qt}l")
+                add("ldsr", f"const bf16x4 bj{j}q{qt}h = lds_tr_ld((a_imghi{x}) + {rb + j * 2048});", after=after, tag=f"RD{j}q{qt}h")
 
+        # image reads of the D stage: two k-steps at a time, ~6 MFMA slots ahead of their consumers (register economy)
+        for j in range(4 * g, 4 * g + 4):
+            rd(j, f"AS1({gn})" if j % 4 < 2 else f"AS3({gn})")
         if g == 0:
-            for j in range(4):
-                rd(j)
             add("vaddr", "const unsigned ao = a_old + s_oldr;", tag="AO")
             for qt in range(2):
                 add("ldsr", f"const f32x4 rold{qt} = lds_ld<f32x4>(ao + {(s * 2 + qt) * 4096});", tag=f"ROLD{qt}")
-        if g == 1:
-            # second-half transposed fragments of the NEXT sub-step (the other parity: last read by this sub-step's first C1 MFMAs)
-            nx = "1" if s == 0 else "n"
-            add("vaddr", f"const unsigned pl1_ = a_trlo + s_x{nx};", tag="PL1")
-            add("vaddr", f"const unsigned ph1_ = a_trhi + s_x{nx};", tag="PH1")
+            # second-half transposed fragments of THIS sub-step (one set: the C1 MFMAs just issued were the last readers of the
+            # previous sub-step's; the first reader of these is C1 of the next group-step)
+            add("vaddr", f"const unsigned pl1_ = a_trlo + s_x{s};", after="CK1b(1)", tag="PL1")
+            add("vaddr", f"const unsigned ph1_ = a_trhi + s_x{s};", after="CK1b(1)", tag="PH1")
             for d in range(2):
-                add("ldsr", f"qT1{nxt}{d} = cat4(lds_tr_ld((pl1_ ^ {64 * d}u) + {16 * 128}), lds_tr_ld((ph1_ ^ {64 * d}u) + {16 * 128}));",
-                    after="CK1b(0)", tag=f"LT1q{d}")
-                add("ldsr", f"oT1{nxt}{d} = cat4(lds_tr_ld((pl1_ ^ {64 * d}u) + {16 * 128} + (OR_ - QR)), lds_tr_ld((ph1_ ^ {64 * d}u) + {16 * 128} + (OR_ - QR)));",
-                    after="CK1b(0)", tag=f"LT1o{d}")
+                add("ldsr", f"qT1d{d} = cat4(lds_tr_ld((pl1_ ^ {64 * d}u) + {16 * 128}), lds_tr_ld((ph1_ ^ {64 * d}u) + {16 * 128}));",
+                    after="CK1b(1)", tag=f"LT1q{d}")
+                add("ldsr", f"oT1d{d} = cat4(lds_tr_ld((pl1_ ^ {64 * d}u) + {16 * 128} + (OR_ - QR)), lds_tr_ld((ph1_ ^ {64 * d}u) + {16 * 128} + (OR_ - QR)));",
+                    after="CK1b(1)", tag=f"LT1o{d}")
         for half in range(2):
             e0 = 8 * half
             pf, dsf = f"pf{half}", f"dsf{half}"
@@ -302,9 +302,6 @@ def sub_step64(s):
                 add("store", "__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rv1), rsWs, rvo + 4096u, 0, 0);", tag="RST1")
             if half == 0 and g == 1 and s == 0:
                 add("dma", "issue_tile();", tag="DMA")
-            if half == 1 and g == 0:
-                for j in range(4, 8):
-                    rd(j)
         if g == 1:
             # first-half transposed fragments of the next sub-step: C0(1) of this one was their last reader
             nx = "1" if s == 0 else "n"
@@ -315,9 +312,8 @@ def sub_step64(s):
                 add("ldsr", f"oT0d{d} = cat4(lds_tr_ld((pl0_ ^ {64 * d}u) + (OR_ - QR)), lds_tr_ld((ph0_ ^ {64 * d}u) + (OR_ - QR)));",
                     after="CK0b(1)", tag=f"LT0o{d}")
         need = {f"CV0a({g})": ["CP3"], f"CK0a({g})": ["CD3"]}
-        if g == 0:
-            for j in range(4):
-                need[f"MD({j},0)"] = [f"RD{j}q1h"]
+        for j in range(4 * g, 4 * g + 4):
+            need[f"MD({j},0)"] = [f"RD{j}q1h"]
         merge(mf, F, need, bundles, issued_m)
     return bundles
 
@@ -326,12 +322,14 @@ def guard(o):
     t = o.tag
     g = None
     if t.startswith("WR"): g = "ABL_NO_WR"
-    elif t in ("AO", "ROLD", "RVO", "RST") or t.startswith("RA"): g = "ABL_NO_WP"
+    elif t in ("AO", "RVO") or t.startswith(("RA", "ROLD", "RST")): g = "ABL_NO_WP"
     elif t.startswith("E") and t[1:].isdigit(): g = "ABL_NO_EXP"
     elif t.startswith("CV") or t.startswith("CK"): g = "ABL_NO_ACC"
     elif t.startswith("MD") or t.startswith("RD"): g = "ABL_NO_MD"
     if g is None:
         return o.code
+    if t.startswith("RST"):
+        return f"\n#if !defined({g}) && !defined(ABL_NO_RST)\n  {o.code}\n#endif\n "
     return f"\n#ifndef {g}\n  {o.code}\n#endif\n "
 
 
@@ -340,6 +338,8 @@ def emit(hd=32):
     report = []
     for s in range(2):
         out.append(f"// ======================== sub-step {s} of the tile ========================")
+        if s == 1:
+            out.append("#ifndef BWD1W_ONLY_SUBSTEP0     // (the half iteration behind the loop: see the kernels)")
         out.append("{")
         bl = sub_step(s) if hd == 32 else sub_step64(s)
         nst = 0
@@ -367,6 +367,8 @@ def emit(hd=32):
         out.append(f"  STAMP({nst + 1});")
         out.append(f"  STAMP_ACCUM({s});")
         out.append("}")
+        if s == 1:
+            out.append("#endif")
     return "\n".join(out) + "\n", report
 
 
