@@ -29,7 +29,9 @@ int octmae_abi_version(void);
 /* Kernel-selection switches for same-process A/B measurements and for tests that cover both forms of a kernel (no reference
  * counterpart: the reference's kernels come from its libraries).  Returns the previous value, -1 for an unknown key.
  *   "attn_bwd_hd32_form"   1 (default): one wave per SIMD, 4 x 128 keys per workgroup (csrc/attn_bwd1w.hip)
- *                          0: two waves per SIMD, 8 x 64 keys (csrc/attn_bwd.hip) -- the round-2 kernel */
+ *                          0: two waves per SIMD, 8 x 64 keys (csrc/attn_bwd.hip) -- the round-2 kernel
+ *   "attn_bwd_hd64_form"   1 (default): one wave per SIMD, 4 x 64 keys per workgroup (csrc/attn_bwd1w64.hip)
+ *                          0: two waves per SIMD, 8 x 32 keys (csrc/attn_bwd.hip); the two forms agree bit for bit */
 int octmae_set_option(const char* key, int value);
 
 /* ---- GEMM with fused epilogues ------------------------------------------------------------------

@@ -319,8 +319,8 @@ ATTN_BWD_FUSED = {32: True, 64: True}
 
 
 def set_option(key: str, value: int) -> int:
-    """octmae_set_option: kernel-selection switch for A/B measurements and tests ("attn_bwd_hd32_form": 1 = one wave per SIMD
-    (default), 0 = the two-waves-per-SIMD kernel).  Returns the previous value."""
+    """octmae_set_option: kernel-selection switch for A/B measurements and tests ("attn_bwd_hd32_form" / "attn_bwd_hd64_form":
+    1 = one wave per SIMD (default), 0 = the two-waves-per-SIMD kernel).  Returns the previous value."""
     from ._lib import load
     prev = load().octmae_set_option(key.encode(), int(value))
     if prev < 0:
