@@ -77,13 +77,13 @@ _PMC_KERNEL = {"gemm_wgrad_epi5": ["gemm256p_kernel<true, true, 5, true>", "gemm
                "attn_fwd_hd32": ["attn_fwd_kernel<32, true>"], "attn_fwd_hd64": ["attn_fwd_kernel<64, true>"],
                "attn_bwd_dq_hd32": ["attn_bwd_dq_kernel<32>"], "attn_bwd_dq_hd64": ["attn_bwd_dq_kernel<64>"],
                "attn_bwd_dkv_hd32": ["attn_bwd_dkv_kernel<32>"], "attn_bwd_dkv_hd64": ["attn_bwd_dkv_kernel<64>"],
-               "attn_bwd_fused_hd32": ["attn_bwd_fused1w_kernel", "attn_bwd_fused_kernel<32>"], "attn_bwd_fused_hd64": ["attn_bwd_fused_kernel<64>"],
+               "attn_bwd_fused_hd32": ["attn_bwd_fused1w_kernel", "attn_bwd_fused_kernel<32>"], "attn_bwd_fused_hd64": ["attn_bwd_fused1w64_kernel", "attn_bwd_fused_kernel<64>"],
                "ln_bwd_d1024": ["ln_bwd_kernel<4>"], "ln_bwd_d512": ["ln_bwd_kernel<2>"],
                "ln_fwd_d1024": ["ln_fwd_kernel<4>"], "ln_fwd_d512": ["ln_fwd_kernel<2>"]}
 # A timed kind that is one C-ABI entry point but several launches: the HIP events bracket the whole entry, so `avg_launch_us`
 # is the SUM of these kernels' average durations in a rocprofv3 summary, and `traffic` the sum of their bytes.
 _LAUNCH_GROUP = {"attn_bwd_fused_hd32": ["attn_rowconst_pad_kernel<32>", "attn_bwd_fused1w_kernel", "attn_bwd_tail1_kernel<32>"],
-                 "attn_bwd_fused_hd64": ["attn_rowconst_pad_kernel<64>", "attn_bwd_fused_kernel<64>", "attn_bwd_tail1_kernel<64>"]}
+                 "attn_bwd_fused_hd64": ["attn_rowconst_pad_kernel<64>", "attn_bwd_fused1w64_kernel", "attn_bwd_tail1_kernel<64>"]}
 # (N = 5121 and 1281 leave ONE key past the last full key block: the single-key tail kernel, attn_bwd_tail1_kernel, runs)
 
 
