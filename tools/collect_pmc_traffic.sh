@@ -11,7 +11,7 @@ OUT=$R/gpurun_out/pmc_traffic
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $R/bench.py --no-cpu-baseline --no-kernel-timing \
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $R/bench.py --no-cpu-baseline --no-kernel-timing \
       --steps 1 --warmup 0 --global-batch $MB --micro-batch $MB > $OUT/$c.log 2>&1
 done
 python3 - "$OUT" "$R/gpurun_out/${ROUND}_pmc_hbm_traffic.json" "$MB" "$HEAD_ID" <<'PY'
