@@ -82,9 +82,10 @@ _PMC_KERNEL = {"gemm_wgrad_epi5": ["gemm256p_kernel<true, true, 5, true>", "gemm
                "ln_fwd_d1024": ["ln_fwd_kernel<4>"], "ln_fwd_d512": ["ln_fwd_kernel<2>"]}
 # A timed kind that is one C-ABI entry point but several launches: the HIP events bracket the whole entry, so `avg_launch_us`
 # is the SUM of these kernels' average durations in a rocprofv3 summary, and `traffic` the sum of their bytes.
-_LAUNCH_GROUP = {"attn_bwd_fused_hd32": ["attn_rowconst_pad_kernel<32>", "attn_bwd_fused1w_kernel", "attn_bwd_tail1_kernel<32>"],
-                 "attn_bwd_fused_hd64": ["attn_rowconst_pad_kernel<64>", "attn_bwd_fused1w64_kernel", "attn_bwd_tail1_kernel<64>"]}
-# (N = 5121 and 1281 leave ONE key past the last full key block: the single-key tail kernel, attn_bwd_tail1_kernel, runs)
+_LAUNCH_GROUP = {"attn_bwd_fused_hd32": ["attn_rowconst_pad_kernel<32>", "attn_bwd_fused1w_kernel"],
+                 "attn_bwd_fused_hd64": ["attn_rowconst_pad_kernel<64>", "attn_bwd_fused1w64_kernel"]}
+# (N = 5121 and 1281 leave ONE key past the last full key block: the one-wave main kernels take it, and the workspace -> bf16
+# conversion, at their end -- attn_bwd_tail1.hpp; until mid round 3 that was a third launch, attn_bwd_tail1_kernel)
 
 
 def pmc_traffic(kind, micro_batch):

@@ -31,7 +31,9 @@ int octmae_abi_version(void);
  *   "attn_bwd_hd32_form"   1 (default): one wave per SIMD, 4 x 128 keys per workgroup (csrc/attn_bwd1w.hip)
  *                          0: two waves per SIMD, 8 x 64 keys (csrc/attn_bwd.hip) -- the round-2 kernel
  *   "attn_bwd_hd64_form"   1 (default): one wave per SIMD, 4 x 64 keys per workgroup (csrc/attn_bwd1w64.hip)
- *                          0: two waves per SIMD, 8 x 32 keys (csrc/attn_bwd.hip); the two forms agree bit for bit */
+ *                          0: two waves per SIMD, 8 x 32 keys (csrc/attn_bwd.hip); the two forms agree bit for bit
+ *   "attn_bwd_tail_fused"  1 (default): the one-wave kernels also take the single key past the last full key block and the
+ *                          workspace -> bf16 conversion of their (batch, head); 0: the separate launch (same results) */
 int octmae_set_option(const char* key, int value);
 
 /* ---- GEMM with fused epilogues ------------------------------------------------------------------

@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "attn_tile.hpp"
+#include "attn_bwd_tail1.hpp"
 #include "../../include/octmae.h"
 
 namespace octmae {
@@ -772,112 +773,18 @@ __global__ __launch_bounds__(256) void attn_bwd_tail1_kernel(const bf16_t* __res
                                                              const float* __restrict__ rowc, const float* __restrict__ dq_ws,
                                                              bf16_t* __restrict__ dqkv, int N, int NPAD, int H, int key, int have_ws,
                                                              float scale) {
-  constexpr int LPR = HD / 8, RPP = 256 / LPR;               // lanes per query row (8 head dims = one 16-byte chunk each), rows per pass
   __shared__ float red[256 * 8];
-  const int tid = threadIdx.x;
-  const int c = tid % LPR, rlane = tid / LPR;
-  const int bh = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-  const int b = bh / H, head = bh % H;
-  const size_t rs = (size_t)3 * H * HD, os = (size_t)H * HD;
-  const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)head * HD + 8 * c;
-  const bf16_t* kb_ = qb + (size_t)H * HD;
-  const bf16_t* vb_ = qb + (size_t)2 * H * HD;
-  const bf16_t* dob = dout + (size_t)b * N * os + (size_t)head * HD + 8 * c;
-  const float* wsb = dq_ws + (size_t)bh * N * HD + 8 * c;
-  bf16_t* dqb = dqkv + (size_t)b * N * rs + (size_t)head * HD + 8 * c;
-  const float* rc_l = rowc + (size_t)bh * NPAD;
-  const float* rc_d = rowc + (size_t)gridDim.x * NPAD + (size_t)bh * NPAD;
-  const float sc2 = scale * LOG2E;
-
-  // this lane's 8 dims of the key: K (raw, for dQ), K * scale * log2e rounded to bf16 (for S), V
-  float kf[8], ksf[8], vf[8];
-  {
-    const u32x4 kw = *reinterpret_cast<const u32x4*>(kb_ + (size_t)key * rs);
-    const u32x4 vw = *reinterpret_cast<const u32x4*>(vb_ + (size_t)key * rs);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      kf[2 * e] = bflo(kw[e]); kf[2 * e + 1] = bfhi(kw[e]);
-      vf[2 * e] = bflo(vw[e]); vf[2 * e + 1] = bfhi(vw[e]);
-      const unsigned ks = pack2bf(bflo(kw[e]) * sc2, bfhi(kw[e]) * sc2);
-      ksf[2 * e] = bflo(ks); ksf[2 * e + 1] = bfhi(ks);
-    }
-  }
-  float dk[8], dv[8];
-#pragma unroll
-  for (int d = 0; d < 8; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
-
-  // one row ahead: the loads of pass i + 1 are requested before pass i is computed
-  auto ld = [&](int q, u32x4& qw, u32x4& ow, f32x4& w0, f32x4& w1, float& cl, float& cd) {
-    const int qq = q < N ? q : N - 1;
-    qw = *reinterpret_cast<const u32x4*>(qb + (size_t)qq * rs);
-    ow = *reinterpret_cast<const u32x4*>(dob + (size_t)qq * os);
-    w0 = f32x4{0.f, 0.f, 0.f, 0.f}; w1 = w0;
-    if (have_ws) {
-      w0 = *reinterpret_cast<const f32x4*>(wsb + (size_t)qq * HD);
-      w1 = *reinterpret_cast<const f32x4*>(wsb + (size_t)qq * HD + 4);
-    }
-    cl = rc_l[qq]; cd = rc_d[qq];
-  };
-  u32x4 qw, ow, nqw, now_;
-  f32x4 w0, w1, nw0, nw1;
-  float cl, cd, ncl, ncd;
-  ld(rlane, qw, ow, w0, w1, cl, cd);
-  for (int q0 = 0; q0 < N; q0 += RPP) {
-    const int q = q0 + rlane;
-    ld(q + RPP, nqw, now_, nw0, nw1, ncl, ncd);
-    float qf[8], of[8];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      qf[2 * e] = bflo(qw[e]); qf[2 * e + 1] = bfhi(qw[e]);
-      of[2 * e] = bflo(ow[e]); of[2 * e + 1] = bfhi(ow[e]);
-    }
-    float sp = 0.f, dpp = 0.f;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) { sp = fmaf(qf[d], ksf[d], sp); dpp = fmaf(of[d], vf[d], dpp); }
-#pragma unroll
-    for (int m = 1; m < LPR; m <<= 1) { sp += __shfl_xor(sp, m, 64); dpp += __shfl_xor(dpp, m, 64); }
-    const bool live = q < N;
-    const float p = live ? fast_exp2(sp + cl) : 0.f;
-    const float ds = p * (dpp + cd);
-    const unsigned pr = pack2bf(p, ds);                       // the MFMA path rounds P (for dV) and dS (for dK, dQ) to bf16
-    const float pb = bflo(pr), dsb = bfhi(pr);
-#pragma unroll
-    for (int d = 0; d < 8; ++d) { dv[d] = fmaf(pb, of[d], dv[d]); dk[d] = fmaf(dsb, qf[d], dk[d]); }
-    if (live) {
-      u32x4 w;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float a0 = fmaf(dsb, kf[2 * e], e < 2 ? w0[2 * e] : w1[2 * e - 4]);
-        const float a1 = fmaf(dsb, kf[2 * e + 1], e < 2 ? w0[2 * e + 1] : w1[2 * e - 3]);
-        w[e] = pack2bf(a0 * scale, a1 * scale);
-      }
-      *reinterpret_cast<u32x4*>(dqb + (size_t)q * rs) = w;
-    }
-    qw = nqw; ow = now_; w0 = nw0; w1 = nw1; cl = ncl; cd = ncd;
-  }
-  // ---- dK, dV of the key: the 256 / LPR row lanes summed in a fixed order
-#pragma unroll
-  for (int which = 0; which < 2; ++which) {
-    __syncthreads();
-#pragma unroll
-    for (int d = 0; d < 8; ++d) red[d * 256 + tid] = which ? dv[d] : dk[d];
-    __syncthreads();
-    if (tid < HD) {
-      const int cc = tid / 8, dd = tid % 8;
-      float acc = 0.f;
-      for (int t = cc; t < 256; t += LPR) acc += red[dd * 256 + t];
-      bf16_t* dst = dqkv + ((size_t)b * N + key) * rs + (size_t)(which ? 2 : 1) * H * HD + (size_t)head * HD + tid;
-      *dst = (bf16_t)(pack2bf(which ? acc : acc * scale, 0.f) & 0xffffu);
-    }
-  }
+  attn_bwd_tail1_body<HD, 1>(qkv, dout, rowc, dq_ws, dqkv, N, NPAD, H, key, have_ws, scale, xcd_remap((int)blockIdx.x, (int)gridDim.x),
+                             (int)gridDim.x, red, (int)threadIdx.x);
 }
 
 // one wave per SIMD, head_dim 32 (attn_bwd1w.hip)
 int launch_attn_bwd_fused1w(const bf16_t* qkv, const bf16_t* dout, const float* rowc, float* dq_ws, bf16_t* dqkv, int B, int N, int NPAD,
-                            int H, int nkb, float scale, hipStream_t st);
+                            int H, int nkb, float scale, int tail_key, hipStream_t st);
 // one wave per SIMD, head_dim 64 (attn_bwd1w64.hip)
 int launch_attn_bwd_fused1w64(const bf16_t* qkv, const bf16_t* dout, const float* rowc, float* dq_ws, bf16_t* dqkv, int B, int N, int NPAD,
-                              int H, int nkb, float scale, hipStream_t st);
+                              int H, int nkb, float scale, int tail_key, hipStream_t st);
+std::atomic<int> g_attn_bwd_tail_fused{1};      // the single-key tail inside the one-wave main kernels (0: its own launch)
 std::atomic<int> g_attn_bwd_hd32_form{1};
 std::atomic<int> g_attn_bwd_hd64_form{1};
 
@@ -897,17 +804,24 @@ static int run_fused(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, con
     OCTMAE_LAUNCH_CHECK();
   }
   const int nkb = N / C::KB;
+  // one key past the last full block: the one-wave main kernels take it (and the workspace -> bf16 conversion) at their end
+  const bool one_key = N - nkb * C::KB == 1;
+  bool tail_done = false;
+  const int tail_key = (one_key && g_attn_bwd_tail_fused.load(std::memory_order_relaxed)) ? nkb * C::KB : -1;
   if (nkb > 0 && HD == 32 && g_attn_bwd_hd32_form.load(std::memory_order_relaxed) == 1) {
-    if (int rc = launch_attn_bwd_fused1w(qkv, dout, rowc, dq_ws, dqkv, B, N, NPAD, H, nkb, scale, st)) return rc;
+    if (int rc = launch_attn_bwd_fused1w(qkv, dout, rowc, dq_ws, dqkv, B, N, NPAD, H, nkb, scale, tail_key, st)) return rc;
+    tail_done = tail_key >= 0;
   } else if (nkb > 0 && HD == 64 && g_attn_bwd_hd64_form.load(std::memory_order_relaxed) == 1) {
-    if (int rc = launch_attn_bwd_fused1w64(qkv, dout, rowc, dq_ws, dqkv, B, N, NPAD, H, nkb, scale, st)) return rc;
+    if (int rc = launch_attn_bwd_fused1w64(qkv, dout, rowc, dq_ws, dqkv, B, N, NPAD, H, nkb, scale, tail_key, st)) return rc;
+    tail_done = tail_key >= 0;
   } else if (nkb > 0) {
     static DynLdsOnce once;
     if (int rc = once.ensure(reinterpret_cast<const void*>(attn_bwd_fused_kernel<HD>), C::LDS)) return rc;
     hipLaunchKernelGGL(attn_bwd_fused_kernel<HD>, dim3(B * H), dim3(512), C::LDS, st, qkv, dout, rowc, dq_ws, dqkv, N, NPAD, H, nkb, scale);
     OCTMAE_LAUNCH_CHECK();
   }
-  if (N - nkb * C::KB == 1) {
+  if (tail_done) return 0;
+  if (one_key) {
     hipLaunchKernelGGL(attn_bwd_tail1_kernel<HD>, dim3(B * H), dim3(256), 0, st, qkv, dout, rowc, dq_ws, dqkv, N, NPAD, H, nkb * C::KB,
                        nkb > 0 ? 1 : 0, scale);
     OCTMAE_LAUNCH_CHECK();
@@ -936,6 +850,7 @@ extern "C" int octmae_set_option(const char* key, int value) {
   if (key == nullptr) return -1;
   if (__builtin_strcmp(key, "attn_bwd_hd32_form") == 0) return g_attn_bwd_hd32_form.exchange(value ? 1 : 0);
   if (__builtin_strcmp(key, "attn_bwd_hd64_form") == 0) return g_attn_bwd_hd64_form.exchange(value ? 1 : 0);
+  if (__builtin_strcmp(key, "attn_bwd_tail_fused") == 0) return g_attn_bwd_tail_fused.exchange(value ? 1 : 0);
   return -1;
 }
 

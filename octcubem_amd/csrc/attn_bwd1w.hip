@@ -15,6 +15,7 @@
 //   * Q / dO / row-constant tiles arrive by LDS-DMA through a 3-deep ring two tiles ahead, retired by counted vmcnt.
 // Reference op: backward of softmax((q k^T) scale) v, Pre-training/custom_util/video_vit.py:130-134 under autograd.
 #include "attn_bwd1w.hpp"
+#include "attn_bwd_tail1.hpp"
 #include "../../include/octmae.h"
 
 namespace octmae {
@@ -64,7 +65,7 @@ __device__ unsigned g_bwd1w_stamp[512 * 4 * 2 * 10];
 __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                   const float* __restrict__ rowc, float* __restrict__ dq_ws,
                                                                   bf16_t* __restrict__ dqkv, int N, int NPAD, int H, int nkb,
-                                                                  float scale) {
+                                                                  float scale, int tail_key) {
   using namespace bwd1w;
   extern __shared__ __attribute__((aligned(128))) char smem[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
   const unsigned s_pcn = (unsigned)(slotn * 512), s_xn = (unsigned)(slotn * T::BYTES);                              \
   const unsigned s_oldr = (unsigned)(((t + 2) % NOLD) * 2 * NW * 1024);                                             \
   const unsigned s_redoff0 = t > 0 ? (unsigned)(t - 1) * WS_TILE : DROP;                                            \
-  const unsigned s_redoff1 = t > 0 ? (unsigned)(t - 1) * WS_TILE + WS_SUB : DROP;                                   \
+  [[maybe_unused]] const unsigned s_redoff1 = t > 0 ? (unsigned)(t - 1) * WS_TILE + WS_SUB : DROP;                                   \
   auto issue_tile = [&]() {                                                                                         \
     const int tn = t + LA;                                                                                          \
     issue(tn < ntiles ? tn : tn - ntiles, tn < ntiles ? tn : ntiles, tn & (NB - 1));                                \
@@ -302,6 +303,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
     // the image region, which every wave has finished reading behind the loop's last barrier
   }
   wait_vm<0>();
+  // ---- the key past the last full block (N = nkb * KB + 1: the cls token) and the workspace -> bf16 conversion, for this
+  // (batch, head), by the workgroup that has just written the workspace rows and streamed Q / dO (attn_bwd_tail1.hpp)
+  if (tail_key >= 0) {
+    __syncthreads();
+    // (the thread id re-derived from the lane count: nothing of the tail's per-lane state lives in registers across the tile loop)
+    const int lane_t = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    attn_bwd_tail1_body<HD, 4>(qkv, dout, rowc, dq_ws, dqkv, N, NPAD, H, tail_key, 1, scale, bh, (int)gridDim.x, reinterpret_cast<float*>(smem),
+                               wid * 64 + lane_t);
+  }
 }
 
 }  // namespace octmae
@@ -317,10 +327,10 @@ extern "C" int octmae_debug_bwd1w_stamps(void* host, int nbytes) {
 // launcher used by attn_bwd.hip's run_fused<32>
 namespace octmae {
 int launch_attn_bwd_fused1w(const bf16_t* qkv, const bf16_t* dout, const float* rowc, float* dq_ws, bf16_t* dqkv, int B, int N, int NPAD,
-                            int H, int nkb, float scale, hipStream_t st) {
+                            int H, int nkb, float scale, int tail_key, hipStream_t st) {
   static DynLdsOnce once;
   if (int rc = once.ensure(reinterpret_cast<const void*>(attn_bwd_fused1w_kernel), bwd1w::LDS)) return rc;
-  hipLaunchKernelGGL(attn_bwd_fused1w_kernel, dim3(B * H), dim3(256), bwd1w::LDS, st, qkv, dout, rowc, dq_ws, dqkv, N, NPAD, H, nkb, scale);
+  hipLaunchKernelGGL(attn_bwd_fused1w_kernel, dim3(B * H), dim3(256), bwd1w::LDS, st, qkv, dout, rowc, dq_ws, dqkv, N, NPAD, H, nkb, scale, tail_key);
   OCTMAE_LAUNCH_CHECK();
   return 0;
 }

@@ -15,6 +15,7 @@
 // The body of the tile loop is generated (tools/gen_attn_bwd1w.py, sub_step64): it fixes the instruction order.
 // Reference op: backward of softmax((q k^T) scale) v, Pre-training/custom_util/video_vit.py:130-134 under autograd.
 #include "attn_bwd1w.hpp"
+#include "attn_bwd_tail1.hpp"
 #include "../../include/octmae.h"
 
 namespace octmae {
@@ -71,7 +72,7 @@ __device__ unsigned g_bwd1w64_stamp[512 * 4 * 2 * 8];      // [6]: the vmcnt wai
 __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w64_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                     const float* __restrict__ rowc, float* __restrict__ dq_ws,
                                                                     bf16_t* __restrict__ dqkv, int N, int NPAD, int H, int nkb,
-                                                                    float scale) {
+                                                                    float scale, int tail_key) {
   using namespace bwd1w64;
   extern __shared__ __attribute__((aligned(128))) char smem[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w64_kernel(const bf16_t
   const unsigned s_pc1 = (unsigned)(slot * 512 + 128), s_pcn = (unsigned)(slotn * 512);                                         \
   const unsigned s_oldr = (unsigned)(((t + 2) % NOLD) * OLD_TILE);                                                              \
   const unsigned s_redoff0 = t > 0 ? (unsigned)(t - 1) * WS_TILE : DROP;                                                        \
-  const unsigned s_redoff1 = t > 0 ? (unsigned)(t - 1) * WS_TILE + WS_SUB : DROP;                                               \
+  [[maybe_unused]] const unsigned s_redoff1 = t > 0 ? (unsigned)(t - 1) * WS_TILE + WS_SUB : DROP;                                               \
   auto issue_tile = [&]() {                                                                                                     \
     const int tn = t + LA;                                                                                                      \
     issue(BWD1W_DMA_TILE(tn), tn < ntiles ? tn : ntiles, tn & (NB - 1));                                                        \
@@ -367,6 +368,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w64_kernel(const bf16_t
     // vector-memory operations complete in issue order); the dK / dV stores above are nobody's input
   }
   wait_vm<0>();
+  // ---- the key past the last full block (N = nkb * KB + 1: the cls token) and the workspace -> bf16 conversion, for this
+  // (batch, head), by the workgroup that has just written the workspace rows and streamed Q / dO (attn_bwd_tail1.hpp)
+  if (tail_key >= 0) {
+    __syncthreads();
+    // (the thread id re-derived from the lane count: nothing of the tail's per-lane state lives in registers across the tile loop)
+    const int lane_t = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    attn_bwd_tail1_body<HD, 4>(qkv, dout, rowc, dq_ws, dqkv, N, NPAD, H, tail_key, 1, scale, bh, (int)gridDim.x, reinterpret_cast<float*>(smem),
+                               wid * 64 + lane_t);
+  }
 #ifdef BWD1W_STAMP
   {
     unsigned long long k1_, r1_;
@@ -389,10 +399,10 @@ namespace octmae {
 
 // launcher used by attn_bwd.hip's run_fused<64>
 int launch_attn_bwd_fused1w64(const bf16_t* qkv, const bf16_t* dout, const float* rowc, float* dq_ws, bf16_t* dqkv, int B, int N, int NPAD,
-                              int H, int nkb, float scale, hipStream_t st) {
+                              int H, int nkb, float scale, int tail_key, hipStream_t st) {
   static DynLdsOnce once;
   if (int rc = once.ensure(reinterpret_cast<const void*>(attn_bwd_fused1w64_kernel), bwd1w64::LDS)) return rc;
-  hipLaunchKernelGGL(attn_bwd_fused1w64_kernel, dim3(B * H), dim3(256), bwd1w64::LDS, st, qkv, dout, rowc, dq_ws, dqkv, N, NPAD, H, nkb, scale);
+  hipLaunchKernelGGL(attn_bwd_fused1w64_kernel, dim3(B * H), dim3(256), bwd1w64::LDS, st, qkv, dout, rowc, dq_ws, dqkv, N, NPAD, H, nkb, scale, tail_key);
   OCTMAE_LAUNCH_CHECK();
   return 0;
 }

@@ -386,6 +386,14 @@ def test_attention_backward_both_forms(HD, N, B, H):
     a, b_ = out[1].double().view(B, N, 3, H * HD), out[0].double().view(B, N, 3, H * HD)
     assert torch.equal(out[1].view(B, N, 3, H * HD)[:, :, 1:], out[0].view(B, N, 3, H * HD)[:, :, 1:]) or rel(a[:, :, 1:], b_[:, :, 1:]) < 1e-3
     assert rel(a[:, :, 0], b_[:, :, 0]) < 3e-3          # dQ: one bf16 rounding of a differently ordered fp32 sum
+    # the key past the last full block (N = 512 m + 1 / 256 m + 1) is taken by the one-wave kernel itself (default) or by a launch
+    # of its own ("attn_bwd_tail_fused" 0): the same arithmetic in the same order
+    prev_t = ops.set_option("attn_bwd_tail_fused", 0)
+    try:
+        d = ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, HD ** -0.5, fused=True)
+    finally:
+        ops.set_option("attn_bwd_tail_fused", prev_t)
+    assert torch.equal(d, out[1])
 
 
 @pytest.mark.parametrize("HD,N", [(64, 333), (32, 1281), (64, 129), (32, 64)])
