@@ -16,6 +16,9 @@
 // Reference op: backward of softmax((q k^T) scale) v, Pre-training/custom_util/video_vit.py:130-134 under autograd.
 #include "attn_bwd1w.hpp"
 #include "attn_bwd_tail1.hpp"
+#ifndef BWD1W_TAIL_DEPTH
+#define BWD1W_TAIL_DEPTH 4      // passes of rows in flight in the single-key tail (8: measured equal)
+#endif
 #include "../../include/octmae.h"
 
 namespace octmae {
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
     __syncthreads();
     // (the thread id re-derived from the lane count: nothing of the tail's per-lane state lives in registers across the tile loop)
     const int lane_t = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    attn_bwd_tail1_body<HD, 4>(qkv, dout, rowc, dq_ws, dqkv, N, NPAD, H, tail_key, 1, scale, bh, (int)gridDim.x, reinterpret_cast<float*>(smem),
+    attn_bwd_tail1_body<HD, BWD1W_TAIL_DEPTH>(qkv, dout, rowc, dq_ws, dqkv, N, NPAD, H, tail_key, 1, scale, bh, (int)gridDim.x, reinterpret_cast<float*>(smem),
                                wid * 64 + lane_t);
   }
 }
