@@ -478,7 +478,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16_t* __
       }
       if (C::PAIR) *reinterpret_cast<f32x4_t*>(smem + C::XCH + wid * 1024 + lane * 16) = own ? acc0 : acc1;
     };
-    using IC0 = std::integral_constant<int, 0>;
     using ICD = std::integral_constant<int, PD + 1>;
 
 #ifdef BWD_STAMP

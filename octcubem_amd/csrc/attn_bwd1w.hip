@@ -33,8 +33,8 @@ using T = Tile<HD>;                                     // 64 rows x 64 B, XOR-s
 constexpr int QR = 0;                                   // Q ring      [NB][4096]
 constexpr int OR_ = QR + NB * T::BYTES;                 // dO ring     [NB][4096]
 constexpr int CR = OR_ + NB * T::BYTES;                 // constants   [NB][2][64] f32
-constexpr int IMG = CR + NB * 512;                      // dS images [2 sub-steps][512 keys][32 queries] bf16 (64-byte rows); wave w
-constexpr int IMG_W = KW * 64;                          //   writes rows 128 w .. 128 w + 127, every wave reads all rows (transposed)
+constexpr int IMG = CR + NB * 512;                      // dS images [2 sub-steps][512 keys][32 queries] bf16 (64-byte rows); wave w writes
+                                                        //   rows 128 w .. 128 w + 127, every wave reads all rows (transposed)
 constexpr int IMG_BUF = KB * 64;
 constexpr int OLD = IMG + 2 * IMG_BUF;                  // workspace values   [NOLD tiles][2 sub-tiles][NW][64 lanes] f32x4
 constexpr int LDS = OLD + NOLD * 2 * NW * 1024;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
 #define BWD1W_TILE_SETUP                                                                                            \
   const int slot = t & (NB - 1), slotn = (t + 1) & (NB - 1);                                                        \
   const unsigned s_pc1 = (unsigned)(slot * 512 + 128), s_x1 = (unsigned)(slot * T::BYTES + 32 * T::ROWB);           \
-  const unsigned s_pcn = (unsigned)(slotn * 512), s_xn = (unsigned)(slotn * T::BYTES);                              \
+  [[maybe_unused]] const unsigned s_pcn = (unsigned)(slotn * 512), s_xn = (unsigned)(slotn * T::BYTES);                              \
   const unsigned s_oldr = (unsigned)(((t + 2) % NOLD) * 2 * NW * 1024);                                             \
   const unsigned s_redoff0 = t > 0 ? (unsigned)(t - 1) * WS_TILE : DROP;                                            \
   [[maybe_unused]] const unsigned s_redoff1 = t > 0 ? (unsigned)(t - 1) * WS_TILE + WS_SUB : DROP;                                   \

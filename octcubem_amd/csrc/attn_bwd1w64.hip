@@ -271,8 +271,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w64_kernel(const bf16_t
     // per-iteration scalars (ring slots, write-out offsets) and the request of tile t + 3 / the workspace values of tile t + 1
 #define BWD1W_TILE_SETUP                                                                                                        \
   const int slot = t & (NB - 1), slotn = (t + 1) & (NB - 1);                                                                    \
-  const unsigned s_x0 = (unsigned)(slot * T::BYTES), s_x1 = s_x0 + 32 * T::ROWB, s_xn = (unsigned)(slotn * T::BYTES);           \
-  const unsigned s_pc1 = (unsigned)(slot * 512 + 128), s_pcn = (unsigned)(slotn * 512);                                         \
+  const unsigned s_x0 = (unsigned)(slot * T::BYTES), s_x1 = s_x0 + 32 * T::ROWB, s_xn [[maybe_unused]] = (unsigned)(slotn * T::BYTES);           \
+  const unsigned s_pc1 = (unsigned)(slot * 512 + 128), s_pcn [[maybe_unused]] = (unsigned)(slotn * 512);                                         \
   const unsigned s_oldr = (unsigned)(((t + 2) % NOLD) * OLD_TILE);                                                              \
   const unsigned s_redoff0 = t > 0 ? (unsigned)(t - 1) * WS_TILE : DROP;                                                        \
   [[maybe_unused]] const unsigned s_redoff1 = t > 0 ? (unsigned)(t - 1) * WS_TILE + WS_SUB : DROP;                                               \
