@@ -342,7 +342,10 @@ def main():
                                "accounting": "algorithmic: attention fwd 4BHN^2hd, bwd 8BHN^2hd (x3 total), GEMM 2*NA*NB*K"}
             out["kernels"] = {k: {"ms": round(v["total_ms"], 3), "avg_us": round(v["avg_us"], 2), "launches": v["launches"],
                                   "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1),
-                                  "executed_tflops": round(v["exec_flops"] / (v["total_ms"] * 1e-3) / 1e12, 1)}
+                                  "executed_tflops": round(v["exec_flops"] / (v["total_ms"] * 1e-3) / 1e12, 1),
+                                  # algorithmic bytes (operands, outputs, what the epilogue reads) over the same time: the
+                                  # fused-epilogue GEMMs sit under both roofs
+                                  "hbm_gbs_algorithmic": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1)}
                               for k, v in sorted(kt.items())}
             att = [k for k in kt if k.startswith("attn_")]
             if att:

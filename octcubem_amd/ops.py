@@ -183,8 +183,14 @@ def _gemm(A, B, C, NA, NB, K, lda, ldb, ldc, a_ks, b_ks, epi, C2=None, bias=None
         call("octmae_gemm_bf16", *args)
     else:
         kind = f"{_GEMM_KIND.get((a_ks, b_ks), 'gemm')}_epi{epi}"
-        KTIMER.launch(kind, 2.0 * NA * NB * K, 2.0 * (NA * K + NB * K) + C.element_size() * NA * NB,
-                      lambda: call("octmae_gemm_bf16", *args))
+        # algorithmic bytes: both operands once, the output, the second output of the GELU epilogue (2), the residual (3) or
+        # pre-activation (4) the epilogue reads
+        nbytes = 2.0 * (NA * K + NB * K) + C.element_size() * NA * NB
+        if epi == 2 and C2 is not None:
+            nbytes += C2.element_size() * NA * NB
+        if epi in (3, 4) and aux is not None:
+            nbytes += aux.element_size() * NA * NB
+        KTIMER.launch(kind, 2.0 * NA * NB * K, nbytes, lambda: call("octmae_gemm_bf16", *args))
 
 
 def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mode: str = "bf16",
@@ -245,7 +251,7 @@ def linear_dgrad(dy: torch.Tensor, w: torch.Tensor, pre: Optional[torch.Tensor] 
         if KTIMER is None:
             call("octmae_linear_dgrad_dgelu", *args)
         else:   # two launches (GEMM + the fold of the partial sums), timed together
-            KTIMER.launch("gemm_dgrad_epi4", 2.0 * K * M * N, 2.0 * (K * N + M * N) + 2.0 * K * M,
+            KTIMER.launch("gemm_dgrad_epi4", 2.0 * K * M * N, 2.0 * (K * N + M * N) + 2.0 * K * M + 2.0 * K * M,      # + the pre-activation read
                           lambda: call("octmae_linear_dgrad_dgelu", *args))
     return dx
 
