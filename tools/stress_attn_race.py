@@ -8,7 +8,7 @@ torch.manual_seed(0)
 side = torch.cuda.Stream()
 junk = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device="cuda")
 cases = []
-for (B, N, H, HD) in ((4, 1281, 16, 64), (2, 5121, 16, 32), (3, 200, 4, 64), (3, 333, 4, 32)):
+for (B, N, H, HD) in ((4, 1281, 16, 64), (2, 5121, 16, 32), (3, 200, 4, 64), (3, 333, 4, 32), (40, 1281, 16, 64), (20, 5121, 16, 32), (3, 2561, 5, 64)):
     qkv = torch.randn(B * N, 3 * H * HD, device="cuda").to(torch.bfloat16); do = torch.randn(B * N, H * HD, device="cuda").to(torch.bfloat16)
     o, lse = ops.attn_fwd(qkv, B, N, H, HD, HD ** -0.5)
     dq = {f: ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, HD ** -0.5, fused=f).clone() for f in (True, False)}   # both backward forms
