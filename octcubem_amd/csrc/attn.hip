@@ -198,6 +198,9 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : ATT_OCC_FWD64)) vo
     }
     const bool alias = (&scur[0] == &snext[0]);
     if (!last && !alias) qk(t + 1, snext);     // MFMA pipe works on S_{t+1} under the exps below
+    // (four add chains per lane; in the optimistic kernel as two v_pk_add_f32 chains: the kernel is bound by VALU cycles -- PMC: the
+    // VALU is busy 82 % of the kernel, the matrix pipe 42 % -- and a packed add costs the cycles of one scalar add; same sums)
+    f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -206,9 +209,10 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : ATT_OCC_FWD64)) vo
         const float p0 = fast_exp2(scur[kb][g]), p1 = fast_exp2(scur[kb][g + 1]);
         const float p2 = fast_exp2(scur[kb][g + 2]), p3 = fast_exp2(scur[kb][g + 3]);
         scur[kb][g] = p0; scur[kb][g + 1] = p1; scur[kb][g + 2] = p2; scur[kb][g + 3] = p3;
-        if (!ONES_SUM) { s0 += p0; s1 += p1; s2 += p2; s3 += p3; }
+        if (!ONES_SUM && FAST) { s01 += f32x2{p0, p1}; s23 += f32x2{p2, p3}; }
+        if (!ONES_SUM && !FAST) { s0 += p0; s1 += p1; s2 += p2; s3 += p3; }
       }
-    if (!ONES_SUM) l_run += (s0 + s1) + (s2 + s3);
+    if (!ONES_SUM) l_run += FAST ? (s01[0] + s01[1]) + (s23[0] + s23[1]) : (s0 + s1) + (s2 + s3);
     // O^T += V^T P^T   (and, head_dim 32, row sums += 1^T P^T on the MFMA pipe)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)

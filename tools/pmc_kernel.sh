@@ -4,10 +4,10 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 SCRIPT=$1; export KFILT=$2
 rm -rf $R/gpurun_out/pmck_*
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/pmck_stats -- python3 $R/$SCRIPT > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/pmck_stats -- python3 $R/$SCRIPT > /dev/null 2>&1
 for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM" "GRBM_GUI_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA"; do
   tag=$(echo $set | cut -c1-14 | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmck_$tag -- python3 $R/$SCRIPT > /dev/null 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmck_$tag -- python3 $R/$SCRIPT > /dev/null 2>&1
 done
 python3 - <<'PY'
 import csv, glob, os, collections
