@@ -271,7 +271,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.gloo_one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    loss_value = float(loss)
+    loss_value = float(loss.detach())
 
     # One-GPU proxy for strong scaling: what ONE rank of an N-GPU run executes per step -- global batch
     # 256 / N in one micro-batch -- timed on this GPU with the same model, optimizer and kernels; the ratio of its rate to the
