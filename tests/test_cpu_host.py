@@ -4,6 +4,7 @@ import ctypes
 import math
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -183,6 +184,14 @@ def test_graft_entry_build_compiles_and_agrees_on_the_abi_number():
     assert int(re.search(r"#define\s+OCTMAE_ABI_VERSION\s+(\d+)", hdr).group(1)) == _lib.load().octmae_abi_version()
     src = open(os.path.join(ROOT, "octcubem_amd", "csrc", "probe.hip")).read()
     assert "return OCTMAE_ABI_VERSION" in src
+
+
+def test_generated_attention_bodies_are_current():
+    """csrc/attn_bwd1w_body.inc and attn_bwd1w_body_hd64.inc (the placed tile bodies of the one-wave-per-SIMD attention backward
+    kernels) are committed so that a build needs no Python; they must be what tools/gen_attn_bwd1w.py produces."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_attn_bwd1w.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
 
 
 def test_native_comm_bootstrap_over_a_store(monkeypatch):

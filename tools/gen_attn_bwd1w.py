@@ -374,13 +374,18 @@ def emit(hd=32):
 
 if __name__ == "__main__":
     text, report = emit(32)
+    text64, report64 = emit(64)
+    OUT64 = OUT.replace("_body.inc", "_body_hd64.inc")
+    if "--check" in sys.argv:      # the committed bodies are what this generator produces (tests/test_cpu_host.py)
+        stale = [p for p, t in ((OUT, text), (OUT64, text64)) if open(p).read() != t]
+        print("stale: " + ", ".join(stale) if stale else "generated bodies are current")
+        sys.exit(1 if stale else 0)
     with open(OUT, "w") as f:
         f.write(text)
     tot = sum(r[4] for r in report)
     nm = sum(1 for r in report if r[2] != "-")
     print(f"wrote {OUT}: {len(report)} bundles, {nm} MFMAs per tile, issue estimate {tot} cycles per tile")
-    text64, report64 = emit(64)
-    with open(OUT.replace("_body.inc", "_body_hd64.inc"), "w") as f:
+    with open(OUT64, "w") as f:
         f.write(text64)
     print(f"wrote the head_dim-64 body: {len(report64)} bundles, issue estimate {sum(r[4] for r in report64)} cycles per tile")
     if "--report64" in sys.argv:
