@@ -4,6 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from octcubem_amd import ops
 B = int(os.environ.get("B", "32"))
 fused = os.environ.get("FUSED", "1") == "1"
+if "FORM" in os.environ:      # 0: the round-2 two-waves-per-SIMD main kernels
+    for hd in (32, 64):
+        ops.set_option(f"attn_bwd_hd{hd}_form", int(os.environ["FORM"]))
 for (N, H, HD) in ((5121, 16, 32), (1281, 16, 64)):
     g = torch.Generator(device="cuda").manual_seed(0)
     qkv = torch.randn(B * N, 3 * H * HD, device="cuda", generator=g).to(torch.bfloat16)
