@@ -270,13 +270,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w64_kernel(const bf16_t
 #endif
     // per-iteration scalars (ring slots, write-out offsets) and the request of tile t + 3 / the workspace values of tile t + 1
 #define BWD1W_TILE_SETUP                                                                                                        \
-  const int slot = t & (NB - 1), slotn = (t + 1) & (NB - 1);                                                                    \
-  const unsigned s_x0 = (unsigned)(slot * T::BYTES), s_x1 = s_x0 + 32 * T::ROWB, s_xn [[maybe_unused]] = (unsigned)(slotn * T::BYTES);           \
-  const unsigned s_pc1 = (unsigned)(slot * 512 + 128), s_pcn [[maybe_unused]] = (unsigned)(slotn * 512);                                         \
-  const unsigned s_oldr = (unsigned)(((t + 2) % NOLD) * OLD_TILE);                                                              \
-  const unsigned s_redoff0 = t > 0 ? (unsigned)(t - 1) * WS_TILE : DROP;                                                        \
+  [[maybe_unused]] const int slot = t & (NB - 1), slotn = (t + 1) & (NB - 1);                                                                    \
+  [[maybe_unused]] const unsigned s_x0 = (unsigned)(slot * T::BYTES), s_x1 = s_x0 + 32 * T::ROWB, s_xn = (unsigned)(slotn * T::BYTES);           \
+  [[maybe_unused]] const unsigned s_pc1 = (unsigned)(slot * 512 + 128), s_pcn = (unsigned)(slotn * 512);                                         \
+  [[maybe_unused]] const unsigned s_oldr = (unsigned)(((t + 2) % NOLD) * OLD_TILE);                                                              \
+  [[maybe_unused]] const unsigned s_redoff0 = t > 0 ? (unsigned)(t - 1) * WS_TILE : DROP;                                                        \
   [[maybe_unused]] const unsigned s_redoff1 = t > 0 ? (unsigned)(t - 1) * WS_TILE + WS_SUB : DROP;                                               \
-  auto issue_tile = [&]() {                                                                                                     \
+  [[maybe_unused]] auto issue_tile = [&]() {                                                                                                     \
     const int tn = t + LA;                                                                                                      \
     issue(BWD1W_DMA_TILE(tn), tn < ntiles ? tn : ntiles, tn & (NB - 1));                                                        \
     oldreq(t + 1, (t + 1) % NOLD, BWD1W_OLD_BASE);                                                                              \
@@ -291,12 +291,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w64_kernel(const bf16_t
 #else
 #define BWD1W_OLD_BASE oldbase
 #endif
-    // The draining iteration t = ntiles: its sub-step 0 finishes tile ntiles - 1 (dK / dV of its second half, dQ of its second
-    // half summed, its first half written out); its sub-step 1 only writes that second half out -- nothing when those 32 rows are
-    // all >= N (N = 64 m + 1 .. 64 m + 32: the cls token makes the model's lengths 64 m + 1).  Then the loop runs the full
-    // iterations and half an iteration follows as straight-line code: no exit from the middle of the loop body.
-    const int nfull = half_drain ? ntiles : ntiles + 1;
-    for (int t = 0; t < nfull; ++t) {
+    // The pipeline drains behind the last real sub-step X of the block -- (ntiles - 1, 0) when rows 32 .. 63 of the last tile are
+    // all >= N (N = 64 m + 1 .. 64 m + 32: the cls token makes the model's lengths 64 m + 1), else (ntiles - 1, 1): one more
+    // sub-step's worth of dV^T / dK^T (X's last group, second half) and the dQ^T product of X, and two write-outs.  Those run as
+    // straight-line code behind the loop, reduced to exactly that (SLIM / TINY, generated from the same bundle table), instead of
+    // as padding sub-steps in full: ~1.7 sub-steps less per key block (of 43 at N = 1281, of 163 at N = 5121).
+    // (the drain code works from opaque copies of the per-lane address constants: derived addresses are then computed there,
+    // not hoisted above the tile loop and kept in registers across it)
+    const unsigned o_imglo = a_imglo, o_imghi = a_imghi, o_old = a_old, o_wsoff = wsoff;
+#define BWD1W_DRAIN_ADDRS \
+  [[maybe_unused]] const unsigned a_imglo = opaque(o_imglo), a_imghi = opaque(o_imghi), a_old = opaque(o_old), wsoff = opaque(o_wsoff);
+    // (here only for lengths whose last tile has no row in its second half -- every length of this model; other lengths drain through
+    // two padding iterations in full: a second copy of the drain code costs this kernel register spills)
+    const int nloop = half_drain ? ntiles - 1 : ntiles + 1;
+    for (int t = 0; t < nloop; ++t) {
 #ifdef BWD1W_STAMP
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sw_[0]));
 #endif
@@ -309,14 +317,32 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w64_kernel(const bf16_t
 #include "attn_bwd1w_body_hd64.inc"
     }
     if (half_drain) {
-      const int t = ntiles;
-      wait_vm<13>();
-      BWD1W_TILE_SETUP
+      {
+        const int t = ntiles - 1;
+        wait_vm<13>();
+        BWD1W_TILE_SETUP
 #define BWD1W_ONLY_SUBSTEP0
 #include "attn_bwd1w_body_hd64.inc"
 #undef BWD1W_ONLY_SUBSTEP0
+      {
+        BWD1W_DRAIN_ADDRS
+#define BWD1W_DRAIN_SLIM1
+#include "attn_bwd1w_drain_hd64.inc"
+#undef BWD1W_DRAIN_SLIM1
+      }
+      }
+      {
+        const int t = ntiles;
+        wait_vm<13>();
+        BWD1W_TILE_SETUP
+        BWD1W_DRAIN_ADDRS
+#define BWD1W_DRAIN_TINY0
+#include "attn_bwd1w_drain_hd64.inc"
+#undef BWD1W_DRAIN_TINY0
+      }
     }
 #undef BWD1W_TILE_SETUP
+#undef BWD1W_DRAIN_ADDRS
 #ifdef BWD1W_STAMP
     if (kb == 1 && lane == 0 && blockIdx.x < 512)
       for (int s_ = 0; s_ < 2; ++s_)

@@ -372,12 +372,44 @@ def emit(hd=32):
     return "\n".join(out) + "\n", report
 
 
+def emit_drain(hd=32):
+    """The pipeline drain behind the last real sub-step X of a key block, instead of padding sub-steps run in full: SLIM(s) is
+    sub-step s reduced to what still has an effect -- dV^T / dK^T of X's last group (second half), the dQ^T product of X from its dS
+    image, the write-out of the tile before -- and TINY(s) is the last write-out alone.  Same instruction order as the full body."""
+    out = ["// GENERATED by tools/gen_attn_bwd1w.py -- do not edit.  Selected by the kernels with BWD1W_DRAIN_SLIM0 / _SLIM1 / _TINY0 / _TINY1."]
+    last_c1 = ("CV1(3)", "CK1(3)") if hd == 32 else ("CV1a(1)", "CV1b(1)", "CK1a(1)", "CK1b(1)")
+    wo = lambda t: t in ("AO", "RVO") or t.startswith(("ROLD", "RA", "RST"))
+    for kind in ("SLIM", "TINY"):
+        for s in range(2):
+            out.append(f"#ifdef BWD1W_DRAIN_{kind}{s}")
+            out.append("{")
+            bl = sub_step(s) if hd == 32 else sub_step64(s)
+            for bi, (m, fill) in enumerate(bl):
+                keep_m = m is not None and kind == "SLIM" and (m.tag in last_c1 or m.tag.startswith("MD("))
+                keep_f = [o for o in fill if wo(o.tag) or (kind == "SLIM" and o.tag.startswith("RD"))]
+                if not keep_m and not keep_f:
+                    continue
+                out.append(f"  // from bundle {bi}")
+                if keep_m:
+                    out.append("  " + guard(m))
+                    out.append("  __builtin_amdgcn_sched_barrier(0);")
+                for o in keep_f:
+                    out.append("  " + guard(o))
+                out.append("  __builtin_amdgcn_sched_barrier(0);")
+            if kind == "SLIM":
+                out.append("  SUBSTEP_END(0);     // every wave is done with the dS image: the epilogue may reuse the region")
+            out.append("}")
+            out.append("#endif")
+    return "\n".join(out) + "\n"
+
+
 if __name__ == "__main__":
     text, report = emit(32)
     text64, report64 = emit(64)
     OUT64 = OUT.replace("_body.inc", "_body_hd64.inc")
+    drains = ((OUT.replace("_body.inc", "_drain.inc"), emit_drain(32)), (OUT.replace("_body.inc", "_drain_hd64.inc"), emit_drain(64)))
     if "--check" in sys.argv:      # the committed bodies are what this generator produces (tests/test_cpu_host.py)
-        stale = [p for p, t in ((OUT, text), (OUT64, text64)) if open(p).read() != t]
+        stale = [p for p, t in ((OUT, text), (OUT64, text64)) + drains if not os.path.exists(p) or open(p).read() != t]
         print("stale: " + ", ".join(stale) if stale else "generated bodies are current")
         sys.exit(1 if stale else 0)
     with open(OUT, "w") as f:
@@ -387,6 +419,9 @@ if __name__ == "__main__":
     print(f"wrote {OUT}: {len(report)} bundles, {nm} MFMAs per tile, issue estimate {tot} cycles per tile")
     with open(OUT64, "w") as f:
         f.write(text64)
+    for p_, t_ in drains:
+        with open(p_, "w") as f:
+            f.write(t_)
     print(f"wrote the head_dim-64 body: {len(report64)} bundles, issue estimate {sum(r[4] for r in report64)} cycles per tile")
     if "--report64" in sys.argv:
         report = report64
