@@ -40,6 +40,13 @@ __device__ __forceinline__ int img_off(int row, int c8) { return row * 64 + ((c8
 // generator pins their last producer), the accumulate chain needs no wait states, and the read-out after the loop sits behind
 // explicit s_nops.
 #define MFMA_ACC(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+// The lane id, computed where it is asked for (volatile: not merged with other copies, not hoisted): code behind the tile loop
+// that needs per-lane addresses derives them from this instead of keeping them -- or the lane id -- in registers across the loop.
+__device__ __forceinline__ int lane_id_fresh() {
+  int x;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+  return x;
+}
 // end of a sub-step: this wave's dS image rows are written (LDS operations complete in order: at most the N reads issued after
 // the last image write may still be pending), then the workgroup barrier
 #ifdef ABL_NO_BARRIER

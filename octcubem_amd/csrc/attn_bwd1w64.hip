@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w64_kernel(const bf16_t
   if (tail_key >= 0) {
     __syncthreads();
     // (the thread id re-derived from the lane count: nothing of the tail's per-lane state lives in registers across the tile loop)
-    const int lane_t = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int lane_t = lane_id_fresh();
     attn_bwd_tail1_body<HD, BWD1W_TAIL_DEPTH>(qkv, dout, rowc, dq_ws, dqkv, N, NPAD, H, tail_key, 1, scale, bh, (int)gridDim.x, reinterpret_cast<float*>(smem),
                                wid * 64 + lane_t);
   }
