@@ -78,19 +78,30 @@ class FusedAdamW(torch.optim.Optimizer):
         self._grad_scale = scale
 
     def zero_grad(self, set_to_none: bool = False):
-        """Gradients are views of one arena: they are zeroed in place, never detached -- and when every gradient of this
-        optimizer is a view of ONE flat buffer (the model's gradient arena), with a single fill of that buffer instead of one
-        launch per parameter (~500 per step for ViT-L)."""
+        """Gradients are views of one arena: they are zeroed in place, never detached -- and when the gradients of this
+        optimizer are views of ONE flat buffer (the model's gradient arena), with one fill per contiguous RUN of them instead
+        of one launch per parameter (~500 per step for ViT-L; a single run when this optimizer holds every trainable
+        parameter).  Only bytes this optimizer owns are touched: two gradients join a run only when the second starts where
+        the first ends or at the next arena alignment boundary, so a slice that belongs to a parameter of another optimizer
+        (or to one that is accumulating for a later step) is never inside a fill."""
         grads = [p.grad for group in self.param_groups for p in group["params"] if p.grad is not None]
         if not grads:
             return
         base = grads[0]._base
-        if base is not None and base.dim() == 1 and all(g._base is base for g in grads) and \
-                sum(g.numel() for g in grads) * 2 >= base.numel():
-            base.zero_()
+        if base is None or base.dim() != 1 or not all(g._base is base and g.is_contiguous() for g in grads):
+            for g in grads:
+                g.zero_()
             return
-        for g in grads:
-            g.zero_()
+        from .arena import ALIGN
+        spans = sorted((g.storage_offset() - base.storage_offset(), g.numel()) for g in grads)
+        start, end = spans[0][0], spans[0][0] + spans[0][1]
+        for o, n in spans[1:]:
+            if o == end or o == (end + ALIGN - 1) // ALIGN * ALIGN:
+                end = o + n
+            else:
+                base[start:end].zero_()
+                start, end = o, o + n
+        base[start:end].zero_()
 
     @torch.no_grad()
     def step(self, closure=None):
