@@ -11,14 +11,16 @@ the data-parallel reducer uses to overlap the RCCL all-reduce with backward.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Optional, Sequence
 
 import torch
 
-from ._lib import call
+from ._lib import call, load
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+_CHECK_IDS = os.environ.get("OCTMAE_CHECK_IDS", "0") == "1"    # verify the permutation contract of the assembly ops per call
 
 EPI_BF16, EPI_F32, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM = range(6)
 
@@ -243,7 +245,6 @@ def linear_dgrad(dy: torch.Tensor, w: torch.Tensor, pre: Optional[torch.Tensor] 
     elif colsum is None or atomic_colsum:
         _gemm(w, dy, dx, K, M, N, w.stride(0), dy.stride(0), K, 1, 0, EPI_DGELU, C2=colsum, aux=pre, ldaux=pre.stride(0))
     else:
-        from ._lib import load
         rows = load().octmae_dgelu_colsum_ws_rows(M)
         ws = torch.empty((rows, K), dtype=F32, device=dy.device)
         args = (w.data_ptr(), dy.data_ptr(), dx.data_ptr(), pre.data_ptr(), ws.data_ptr(), colsum.data_ptr(), M, N, K, w.stride(0),
@@ -293,7 +294,6 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None, want_bf16=
     M, D = x.shape
     dx = torch.empty((M, D), dtype=F32, device=x.device)
     dxb = torch.empty((M, D), dtype=BF16, device=x.device) if want_bf16 else None
-    from ._lib import load
     ws = torch.empty((load().octmae_layernorm_bwd_ws_floats(M, D),), dtype=F32, device=x.device)
     # algorithmic HBM bytes: dy bf16 + x fp32 read, dx fp32 written, + the incoming residual-stream gradient (fp32) and the bf16
     # copy of dx when the fused forms are used
@@ -327,7 +327,6 @@ ATTN_BWD_FUSED = {32: True, 64: True}
 def set_option(key: str, value: int) -> int:
     """octmae_set_option: kernel-selection switch for A/B measurements and tests ("attn_bwd_hd32_form" / "attn_bwd_hd64_form":
     1 = one wave per SIMD (default), 0 = the two-waves-per-SIMD kernel).  Returns the previous value."""
-    from ._lib import load
     prev = load().octmae_set_option(key.encode(), int(value))
     if prev < 0:
         raise RuntimeError(f"octmae_set_option: unknown key {key!r}")
@@ -341,7 +340,6 @@ def attn_bwd(qkv, o, dout, lse, B, N, H, HD, scale, fused: Optional[bool] = None
     st = _stream()
     unit = 2.0 * B * H * N * N * HD
     if ATTN_BWD_FUSED[HD] if fused is None else fused:
-        from ._lib import load
         kib = load().octmae_attn_bwd_fused_ws_kib(B, N, H, HD)
         if kib < 0:
             raise RuntimeError("octmae_attn_bwd_fused_ws_kib: unsupported shape")
@@ -679,13 +677,21 @@ class EncAssembleFn(torch.autograd.Function):
     def forward(ctx, tok, pos, cls, pos_cls, ids_keep, ids_restore=None):
         Bn, nkeep = ids_keep.shape
         D = tok.shape[-1]
-        _chk(tok, BF16, "tokens")
+        _chk(tok, BF16, "tokens"); _chk(ids_keep, torch.int64, "ids_keep")
         pos2 = _chk(pos.reshape(-1, D), F32, "pos table")
         x = torch.empty((Bn, nkeep + 1, D), dtype=F32, device=tok.device)
         call("octmae_enc_assemble", tok.data_ptr(), pos2.data_ptr(), cls.data_ptr(), pos_cls.data_ptr(), ids_keep.data_ptr(),
              x.data_ptr(), Bn, nkeep, D, _stream())
         if ids_restore is not None and (ids_restore.shape[0] != Bn or ids_restore.shape[1] != pos2.shape[0] or Bn > 1024 or D % 4):
             ids_restore = None
+        if ids_restore is not None:
+            # contract of octmae_scatter_add_rows: ids_restore is the inverse of the shuffle whose first nkeep entries are ids_keep
+            # (source row of table row l = its rank ids_restore[b, l], when < nkeep); type / layout are checked here, the
+            # permutation property by tests/test_gpu_kernels.py (and by OCTMAE_CHECK_IDS=1 on every call)
+            _chk(ids_restore, torch.int64, "ids_restore")
+            if _CHECK_IDS and not torch.equal(ids_restore.gather(1, ids_keep),
+                                              torch.arange(nkeep, device=tok.device).expand(Bn, -1)):
+                raise RuntimeError("EncAssembleFn: ids_restore is not the inverse permutation of ids_keep")
         ctx.save_for_backward(ids_keep, ids_restore if ids_restore is not None else ids_keep.new_empty(0))
         ctx.has_restore = ids_restore is not None
         ctx.pos_shape, ctx.cls_shape, ctx.pc_shape = pos.shape, cls.shape, pos_cls.shape
@@ -720,7 +726,9 @@ class DecAssembleFn(torch.autograd.Function):
         Bn, L = ids_restore.shape
         nkeep = ids_keep.shape[1]
         D = emb.shape[-1]
-        _chk(emb, BF16, "decoder tokens")
+        _chk(emb, BF16, "decoder tokens"); _chk(ids_restore, torch.int64, "ids_restore"); _chk(ids_keep, torch.int64, "ids_keep")
+        if _CHECK_IDS and not torch.equal(ids_restore.gather(1, ids_keep), torch.arange(nkeep, device=emb.device).expand(Bn, -1)):
+            raise RuntimeError("DecAssembleFn: ids_restore is not the inverse permutation of ids_keep")
         dpos2 = _chk(dpos.reshape(-1, D), F32, "decoder pos table")
         x = torch.empty((Bn, L + 1, D), dtype=F32, device=emb.device)
         call("octmae_dec_assemble", emb.data_ptr(), mask_token.data_ptr(), dpos2.data_ptr(), _p(dcls), dpos_cls.data_ptr(),
