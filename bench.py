@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--gloo-one-gpu", action="store_true",
                     help="diagnostic: every rank on GPU 0, exchange over gloo -- exercises the multi-rank control flow of this script on "
                          "a one-GPU box (RCCL refuses two ranks on one device); the number it prints is not a benchmark")
+    ap.add_argument("--same-data", action="store_true",
+                    help="diagnostic: every rank draws the SAME volumes (seed without the rank) -- with identical weights and masking "
+                         "noise the ranks' losses must then be bit-equal (comm.last_loss_min_max_over_ranks)")
     args = ap.parse_args()
 
     # ONE line on stdout: RCCL prints a version banner to stdout when a communicator is created (NCCL_DEBUG=VERSION/WARN), and
@@ -158,17 +161,23 @@ def main():
         # torch.distributed is the control plane only (its store carries the RCCL unique id): no device_id, so its own NCCL
         # communicator is created lazily -- i.e. never, unless the native communicator cannot be built.
         dist.init_process_group(backend="gloo" if args.gloo_one_gpu else "nccl", rank=rank, world_size=world)
-        try:
-            if args.torch_nccl or args.gloo_one_gpu:
-                raise RuntimeError("--gloo-one-gpu" if args.gloo_one_gpu else "--torch-nccl")
-            comm = ocomm.NativeComm.from_store(dist.distributed_c10d._get_default_store(), rank, world, local_rank)
+        # ONE backend on the data path, chosen by the command line and never by what happens to work: the native communicator
+        # (default), torch.distributed's NCCL group (--torch-nccl, for comparison) or gloo (--gloo-one-gpu, diagnostic).  If the
+        # native communicator cannot be created the run FAILS (non-zero exit on every rank): a scaling run that silently measured
+        # another backend would be worse than no number.
+        if args.gloo_one_gpu:
+            comm_kind = "torch.distributed gloo (--gloo-one-gpu: diagnostic, every rank on GPU 0)"
+        elif args.torch_nccl:
+            comm_kind = "torch.distributed nccl (--torch-nccl)"
+        else:
+            try:
+                comm = ocomm.NativeComm.from_store(dist.distributed_c10d._get_default_store(), rank, world, local_rank)
+            except Exception as e:
+                print(f"[bench] rank {rank}: FATAL: the native RCCL communicator (octmae_comm_*) could not be created: {e!r}.  "
+                      "Pass --torch-nccl to measure torch.distributed's NCCL group instead.", file=sys.stderr, flush=True)
+                sys.exit(3)
             ocomm.set_default(comm)
             comm_kind = "octmae_comm (RCCL behind the C ABI)"
-        except Exception as e:      # both are RCCL over xGMI; the line says which one ran
-            print(f"[bench] rank {rank}: native RCCL communicator unavailable ({e}); using torch.distributed's", file=sys.stderr,
-                  flush=True)
-            comm = None
-            comm_kind = f"torch.distributed {'gloo' if args.gloo_one_gpu else 'nccl'} (native communicator not used: {e})"
 
     assert args.global_batch % world == 0
     per_rank = args.global_batch // world
@@ -187,7 +196,7 @@ def main():
     torch.manual_seed(0)                                   # identical initial weights on every rank
     model = models_mae.octcube_vit_large_3dmae().to(dev)
     model.train()
-    reducer = FlatGradReducer(model, force=args.force_reducer, comm=comm) if use_dist else None
+    reducer = FlatGradReducer(model, force=args.force_reducer, comm=comm, allow_torch_nccl=args.torch_nccl) if use_dist else None
     model.prepare()
     if reducer is not None:
         reducer.broadcast_parameters(0)
@@ -216,7 +225,8 @@ def main():
         per = global_batch // world
         assert per % mb == 0
         accum_ = per // mb
-        g = torch.Generator(device=dev).manual_seed(1234 + rank)   # rank r sees different volumes (seed + rank, main_pretrain…:306)
+        # rank r sees different volumes (seed + rank, main_pretrain…:306)
+        g = torch.Generator(device=dev).manual_seed(1234 + (0 if args.same_data else rank))
         pool_ = [torch.rand(mb, 1, 60, 256, 256, device=dev, generator=g) for _ in range(min(accum_, 2))]
 
         def step_(exchange=True):
@@ -272,6 +282,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_value = float(loss.detach())
+    # every rank counts itself in through the SAME backend the gradients went through: ranks_seen must equal n_gpus
+    if comm is not None:
+        ranks_seen = int(round(comm.all_reduce_scalar(1.0, ocomm.SUM)))
+        loss_minmax = (comm.all_reduce_scalar(-loss_value, ocomm.MAX), comm.all_reduce_scalar(loss_value, ocomm.MAX))
+        loss_minmax = (-loss_minmax[0], loss_minmax[1])
+    elif use_dist:
+        t = torch.tensor([1.0, -loss_value, loss_value], dtype=torch.float64, device="cpu" if args.gloo_one_gpu else dev)
+        t1 = t[:1].clone(); dist.all_reduce(t1, op=dist.ReduceOp.SUM)
+        t2 = t[1:].clone(); dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        ranks_seen, loss_minmax = int(round(float(t1[0]))), (-float(t2[0]), float(t2[1]))
+    else:
+        ranks_seen, loss_minmax = 1, (loss_value, loss_value)
 
     # One-GPU proxy for strong scaling: what ONE rank of an N-GPU run executes per step -- global batch
     # 256 / N in one micro-batch -- timed on this GPU with the same model, optimizer and kernels; the ratio of its rate to the
@@ -363,7 +385,11 @@ def main():
                 red = dict(reducer.stats)
                 red["chunk_mb"] = [round(4 * (e - s_) / 1e6, 1) for s_, e in reducer.bounds]
                 red["cold_chunk"] = [bool(c) for c in reducer.cold_chunk]
-            out["comm"] = {"backend": comm_kind, "reducer": red}
+                red["transport"] = reducer.transport
+            out["comm"] = {"backend": comm_kind, "ranks_seen": ranks_seen, "agreed_micro_batch": mb, "reducer": red,
+                           # ranks see different volumes (seed + rank), so their last-step losses differ slightly; identical
+                           # weights after the exchange keep them within sampling noise of each other
+                           "last_loss_min_max_over_ranks": list(loss_minmax)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()

@@ -36,10 +36,14 @@ from . import ops
 
 class FlatGradReducer:
     def __init__(self, model, n_chunks: int = 8, process_group=None, average: bool = True, overlap: bool = True,
-                 force: bool = False, comm=None):
+                 force: bool = False, comm=None, allow_torch_nccl: bool = False):
         self.model = model
         self.group = process_group
         self.comm = comm            # comm.NativeComm (GPU) or None (torch.distributed)
+        # The transport is fixed HERE, by the caller, and never changes behind its back: a NativeComm -> octmae_comm_* (RCCL behind
+        # the C ABI); none -> torch.distributed (gloo for the CPU tests and the one-GPU diagnostic).  GPU gradients over
+        # torch.distributed's own NCCL group -- a second RCCL backend on the data path -- only when asked for by name.
+        self.allow_torch_nccl = allow_torch_nccl
         if comm is not None:
             self.world = comm.world
         else:
@@ -62,6 +66,13 @@ class FlatGradReducer:
         self.multi_use = False
         self._expected = None       # id(param) -> reports per backward, learned
         self._reports = {}
+        # Launch ORDER.  Every rank must enqueue the chunks' collectives in the same order (RCCL / gloo match collectives by
+        # sequence, not by buffer): the order of the first step on the frozen layout is compared across ranks once (one small
+        # MAX all-reduce, host-blocking, in that step's finish()) and from then on every launch is checked locally against it --
+        # a rank whose backward reports gradients in another order RAISES before it enqueues a mismatched collective, instead
+        # of hanging the node or averaging the wrong slices.
+        self._order_learned = None  # tuple of chunk indices in launch order, agreed across ranks (frozen layout only)
+        self._order_now: List[int] = []
         self.stats = {"launched_in_backward": 0, "launched_in_finish": 0, "bytes_in_finish": 0, "bytes_total": 0,
                       "last_launch_bytes": 0}
 
@@ -113,6 +124,10 @@ class FlatGradReducer:
             for name, p, o, n in arena.entries:
                 if p.requires_grad:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._autograd_hook))
+        if arena.grad.is_cuda and self.comm is None and self.world > 1 and not self.allow_torch_nccl \
+                and dist.get_backend(self.group) == "nccl":
+            raise RuntimeError("FlatGradReducer: GPU gradients and no NativeComm -- pass comm=NativeComm.from_env() (the octmae_comm_* "
+                               "RCCL path) or allow_torch_nccl=True to exchange through torch.distributed's NCCL group on purpose")
         if arena.grad.is_cuda and self.comm is None and self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=arena.grad.device)
 
@@ -127,6 +142,7 @@ class FlatGradReducer:
         self._pending = []
         self._in_backward = True
         self._reports = {}
+        self._order_now = []
         self._overlap_now = self._sync and self.overlap and not (self.multi_use and self._expected is None)
         ops.add_grad_ready_callback(self, self._on_ready if self._overlap_now else self._on_ready_note)
         if self._overlap_now and self._frozen:
@@ -174,6 +190,16 @@ class FlatGradReducer:
     def _launch(self, c: int):
         if self._launched[c]:
             return
+        if self._order_learned is not None:
+            i = len(self._order_now)
+            if i >= len(self._order_learned) or self._order_learned[i] != c:
+                exp = self._order_learned[i] if i < len(self._order_learned) else None
+                raise RuntimeError(f"FlatGradReducer: gradient chunk {c} became ready as launch #{i} of this backward, but the order "
+                                   f"agreed across ranks has chunk {exp} there -- this rank's control flow diverged from the step the "
+                                   "schedule was learned from (collectives are matched by sequence: exchanging now would hang or "
+                                   "average the wrong slices).  Call reducer.relearn() on EVERY rank before a step whose backward "
+                                   "differs")
+        self._order_now.append(c)
         self._launched[c] = True
         s, e = self.bounds[c]
         buf = self._arena.grad[s:e]
@@ -224,34 +250,64 @@ class FlatGradReducer:
         self._reports = {}
         # learning step: whoever reported on no rank is "cold"; agreed across ranks once, then frozen
         if self.overlap and not self._frozen:
+            self._agree_order(learn=False)      # the learning step's own launches must already have matched
             self._cold = self._agree_cold()
             self._frozen = True
             self._layout(rebuild=True)
+        elif self._order_learned is None and (not self.overlap or self._frozen):
+            self._agree_order(learn=True)       # first step on the final layout: agree, then check locally ever after
 
     def relearn(self):
         """Forget the readiness layout: the next exchanged backward is a learning step again (no early launches)."""
         self._cold = frozenset()
         self._frozen = False
+        self._order_learned = None
         if self._arena is not None:
             self._layout(rebuild=True)
+
+    def _allreduce_max_host(self, v: torch.Tensor) -> torch.Tensor:
+        """MAX over ranks of a small fp32 host vector through the reducer's own transport (host-blocking)."""
+        if not (self.world > 1 or self.force):
+            return v
+        if self.comm is not None:
+            from . import comm as C
+            d = v.to(self._arena.grad.device)
+            self.comm.all_reduce_async(d, C.MAX)
+            self.comm.wait()
+            return d.cpu()
+        if dist.is_initialized():
+            d = v.to(self._arena.grad.device) if self._arena.grad.is_cuda and dist.get_backend(self.group) == "nccl" else v.clone()
+            dist.all_reduce(d, op=dist.ReduceOp.MAX, group=self.group)
+            return d.cpu()
+        return v
+
+    def _agree_order(self, learn: bool):
+        """Compare this backward's launch order across ranks (max(v) == -max(-v) element-wise); learn=True also makes it the
+        order every later backward is checked against locally."""
+        order = list(self._order_now)
+        v = torch.tensor([float(len(order))] + [float(c) for c in order], dtype=torch.float32)
+        n = len(self.bounds) + 1
+        v = torch.cat([v, torch.full((max(0, n - v.numel()),), -1.0)])[:n]
+        m = self._allreduce_max_host(torch.cat([v, -v]))
+        if not torch.equal(m[:n], -m[n:]):
+            raise RuntimeError("FlatGradReducer: the ranks launched their gradient chunks in different orders in this backward "
+                               f"(this rank: {order}); the exchanged gradients of this step are not trustworthy -- every rank must "
+                               "run the same control flow")
+        if learn:
+            self._order_learned = tuple(order)
 
     def _agree_cold(self):
         """ids of the parameters no rank saw a gradient for in the backward just finished (one small MAX all-reduce; the
         only host-blocking exchange of the reducer, once per learning step)."""
         keys = [id(p) for _, p, _, _ in self._arena.entries if p.requires_grad and id(p) in self.chunk_of]
-        mask = torch.tensor([1.0 if k in self._seen else 0.0 for k in keys], dtype=torch.float32)
-        if self.world > 1 or self.force:
-            if self.comm is not None:
-                from . import comm as C
-                dmask = mask.to(self._arena.grad.device)
-                self.comm.all_reduce_async(dmask, C.MAX)
-                self.comm.wait()
-                mask = dmask.cpu()
-            elif dist.is_initialized():
-                dmask = mask.to(self._arena.grad.device) if self._arena.grad.is_cuda else mask
-                dist.all_reduce(dmask, op=dist.ReduceOp.MAX, group=self.group)
-                mask = dmask.cpu()
+        mask = self._allreduce_max_host(torch.tensor([1.0 if k in self._seen else 0.0 for k in keys], dtype=torch.float32))
         return frozenset(k for k, v in zip(keys, mask.tolist()) if v == 0.0)
+
+    @property
+    def transport(self) -> str:
+        if self.comm is not None:
+            return "octmae_comm"
+        return f"torch.distributed/{dist.get_backend(self.group)}" if dist.is_initialized() else "none (single process)"
 
     def exposed_bytes_last_step(self) -> int:
         """Bytes whose all-reduce could only start in finish() (nothing of backward left to hide it), summed over all steps

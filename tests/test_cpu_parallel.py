@@ -66,13 +66,6 @@ def _worker(rank, world, port, q):
     red.finish()
     out = {"rank": rank, "flat0": flat0, "after_micro": after_micro, "grad": arena.grad.clone(), "local": local,
            "offsets": [(e[2], e[3]) for e in arena.entries]}
-    # --- autograd-hook route (PyTorch-side parameters): backward through real autograd
-    arena.grad.zero_()
-    red.begin_backward(sync=True)
-    loss = sum((p * (rank + 1)).sum() for p in arena.params[:3])
-    loss.backward()
-    red.finish()
-    out["grad_hook"] = arena.grad.clone()
     # --- frozen readiness layout: parameter 5 reported on no rank in the learning step, so its chunk goes out at
     # begin_backward(); a gradient for it after that is a change of control flow and must fail loudly
     out["frozen"] = bool(red._frozen and id(arena.params[5]) in red._cold)
@@ -91,6 +84,16 @@ def _worker(rank, world, port, q):
     red.finish()
     out["finish_launches"] = red.stats["launched_in_finish"] - f0
     out["grad_frozen"] = arena.grad.clone()
+    # --- autograd-hook route (PyTorch-side parameters): backward through real autograd.  Only three parameters take part: a
+    # different control flow from the steps above, so every rank calls relearn() first (without it the launch-order check
+    # of the frozen layout raises, see test_control_flow_divergence_raises_instead_of_hanging)
+    red.relearn()
+    arena.grad.zero_()
+    red.begin_backward(sync=True)
+    loss = sum((p * (rank + 1)).sum() for p in arena.params[:3])
+    loss.backward()
+    red.finish()
+    out["grad_hook"] = arena.grad.clone()
     # by value (numpy), not as shared-memory handles: a handle needs this process alive when the parent unpickles it
     out = {k: (v.numpy() if isinstance(v, torch.Tensor) else [t.numpy() for t in v] if k == "local" else v) for k, v in out.items()}
     q.put(out)
@@ -193,3 +196,195 @@ def test_two_reducers_share_one_backward_gloo_world2():
         assert p.exitcode == 0
     for o in outs:
         assert o["ok"], o["why"]
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# world sizes 4 and 8: what an 8-rank launch runs, except RCCL itself
+# ------------------------------------------------------------------------------------------------------------------------
+def _run_children(target, world, extra=(), timeout_s=150):
+    """Start `world` spawn-children, collect one result each; whatever happens, no child outlives this function (children
+    are ended by their own PIDs)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(extra)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = []
+    try:
+        import queue as _q
+        import time as _t
+        deadline = _t.time() + timeout_s
+        while len(outs) < world and _t.time() < deadline:
+            try:
+                outs.append(q.get(timeout=1.0))
+            except _q.Empty:
+                if all(not p.is_alive() for p in procs) and q.empty():
+                    break
+        for p in procs:
+            p.join(timeout=20)
+    finally:
+        alive = [p for p in procs if p.is_alive()]
+        for p in alive:
+            p.terminate()
+        for p in alive:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+    return sorted(outs, key=lambda o: o["rank"]), [p.exitcode for p in procs], bool(alive)
+
+
+def _worker_world(rank, world, port, q):
+    from datetime import timedelta
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=60))
+    from octcubem_amd import ops
+    from octcubem_amd.parallel import FlatGradReducer
+    shapes = [(24, 20), (130,), (40, 30), (30,), (1, 1, 16), (500,), (64, 64), (7,)]
+    arena = FakeArena(shapes, seed=100 + rank)
+    red = FlatGradReducer(FakeModel(arena), n_chunks=4)
+    red.broadcast_parameters(0)
+    res = {"rank": rank, "ok": True, "why": "", "flat_sum": float(arena.flat.double().sum())}
+
+    def fail(msg):
+        res["ok"] = False; res["why"] += " | " + msg
+
+    def expect(step, vals):
+        """vals[i]: expected (mean over ranks) constant in parameter i's gradient slice."""
+        for i, (nm, p, off, n) in enumerate(arena.entries):
+            if not torch.allclose(arena.grad[off:off + n], torch.full((n,), float(vals[i])), atol=1e-6):
+                fail(f"{step}: p{i} holds {float(arena.grad[off])} expected {vals[i]}")
+
+    mean_rank = sum(range(1, world + 1)) / world
+    # ---- step 1 (learning): p7 never reports; p0 reports ONLY on the last rank, as the very last notification, so the
+    # launch order is the same everywhere; the agreed cold set must hold p7 and must NOT hold p0 (MAX over ranks)
+    arena.grad.zero_()
+    red.begin_backward(sync=True)
+    for i in range(6, 0, -1):
+        arena.params[i].grad.add_(float(rank + 1)); ops.notify_grad_ready([arena.params[i]])
+    if rank == world - 1:
+        arena.params[0].grad.add_(float(world)); ops.notify_grad_ready([arena.params[0]])
+    red.finish()
+    expect("learning", [1.0] + [mean_rank] * 6 + [0.0])
+    cold = {i for i, p in enumerate(arena.params) if id(p) in red._cold}
+    if cold != {7} or not red._frozen:
+        fail(f"cold set {cold}, frozen {red._frozen}")
+    # ---- step 2: frozen layout; the cold chunk goes out at begin_backward(); the launch order is agreed in finish()
+    arena.grad.zero_()
+    b0 = red.stats["launched_in_backward"]
+    red.begin_backward(sync=True)
+    early = red.stats["launched_in_backward"] - b0
+    for i in range(6, -1, -1):
+        arena.params[i].grad.add_(float(rank + 1)); ops.notify_grad_ready([arena.params[i]])
+    red.finish()
+    expect("frozen", [mean_rank] * 7 + [0.0])
+    if early < 1 or red._order_learned is None or len(red._order_learned) != len(red.bounds):
+        fail(f"early {early}, order {red._order_learned}, chunks {len(red.bounds)}")
+    # ---- step 3: accumulation -- the micro-step exchanges nothing (gradients stay local), the last one exchanges the sum
+    arena.grad.zero_()
+    bt = red.stats["bytes_total"]
+    red.begin_backward(sync=False)
+    for i in range(6, -1, -1):
+        arena.params[i].grad.add_(float(rank + 1)); ops.notify_grad_ready([arena.params[i]])
+    red.finish()
+    if red.stats["bytes_total"] != bt:
+        fail("an accumulation micro-step exchanged")
+    for i, (nm, p, off, n) in enumerate(arena.entries[:7]):
+        if not torch.equal(arena.grad[off:off + n], torch.full((n,), float(rank + 1))):
+            fail(f"micro-step: p{i} not local")
+    red.begin_backward(sync=True)
+    for i in range(6, -1, -1):
+        arena.params[i].grad.add_(float(rank + 1)); ops.notify_grad_ready([arena.params[i]])
+    red.finish()
+    expect("accumulated", [2 * mean_rank] * 7 + [0.0])
+    # ---- a gradient for the cold parameter on the frozen layout raises (its chunk went out at begin_backward()) ...
+    arena.grad.zero_()
+    red.begin_backward(sync=True)
+    try:
+        arena.params[7].grad.add_(1.0); ops.notify_grad_ready([arena.params[7]])
+        fail("late gradient for a cold parameter did not raise")
+    except RuntimeError:
+        pass
+    arena.params[7].grad.zero_()
+    for i in range(6, -1, -1):
+        arena.params[i].grad.add_(float(rank + 1)); ops.notify_grad_ready([arena.params[i]])
+    red.finish()
+    expect("after the refused gradient", [mean_rank] * 7 + [0.0])
+    # ---- ... and relearn() (on every rank) makes the changed control flow legal: p7 now reports, first of all
+    red.relearn()
+    for step in ("relearn/learning", "relearn/frozen", "relearn/checked"):
+        arena.grad.zero_()
+        red.begin_backward(sync=True)
+        for i in range(7, -1, -1):
+            arena.params[i].grad.add_(float(rank + 1)); ops.notify_grad_ready([arena.params[i]])
+        red.finish()
+        expect(step, [mean_rank] * 8)
+    if red._cold or red._order_learned is None:
+        fail(f"after relearn: cold {len(red._cold)}, order {red._order_learned}")
+    res["grad_sum"] = float(arena.grad.double().sum())
+    q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("world", [4, 8])
+def test_flat_grad_reducer_gloo_world_4_and_8(world):
+    outs, codes, killed = _run_children(_worker_world, world)
+    assert not killed and len(outs) == world and all(c == 0 for c in codes), (len(outs), codes, killed)
+    for o in outs:
+        assert o["ok"], (o["rank"], o["why"])
+    assert len({o["flat_sum"] for o in outs}) == 1           # the broadcast made the weights identical
+    assert len({o["grad_sum"] for o in outs}) == 1           # every rank holds the same exchanged gradient
+
+
+def _worker_diverge(rank, world, port, q):
+    """Frozen layout, launch order agreed; then rank 1 runs its backward in another order.  It must raise BEFORE it enqueues a
+    collective the others would not match; the others may fail (peer gone / time-out) but nobody may hang."""
+    from datetime import timedelta
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=15))
+    from octcubem_amd import ops
+    from octcubem_amd.parallel import FlatGradReducer
+    shapes = [(24, 20), (130,), (40, 30), (30,), (500,), (64, 64)]
+    arena = FakeArena(shapes, seed=3)
+    red = FlatGradReducer(FakeModel(arena), n_chunks=3)
+    for _ in range(2):                      # learning step + the step that agrees on the order
+        arena.grad.zero_()
+        red.begin_backward(sync=True)
+        for p in reversed(arena.params):
+            p.grad.add_(1.0); ops.notify_grad_ready([p])
+        red.finish()
+    res = {"rank": rank, "learned": red._order_learned is not None, "raised": None, "peer_error": None}
+    dist.barrier()
+    arena.grad.zero_()
+    try:
+        red.begin_backward(sync=True)
+        order = list(arena.params) if rank == 1 else list(reversed(arena.params))      # rank 1: forward order
+        for p in order:
+            p.grad.add_(1.0); ops.notify_grad_ready([p])
+        red.finish()
+    except RuntimeError as e:
+        if "control flow diverged" in str(e):
+            res["raised"] = str(e)[:80]
+        else:
+            res["peer_error"] = type(e).__name__ + ": " + str(e)[:120]
+    except Exception as e:                  # gloo reports a vanished peer in several ways
+        res["peer_error"] = type(e).__name__ + ": " + str(e)[:120]
+    q.put(res)
+    q.close(); q.join_thread()              # the feeder thread must have written the result before the process ends
+    # no barrier, no destroy: the group is broken by design; the process just ends
+    os._exit(0)
+
+
+@pytest.mark.timeout(180)
+def test_control_flow_divergence_raises_instead_of_hanging():
+    outs, codes, killed = _run_children(_worker_diverge, 4, timeout_s=90)
+    by_rank = {o["rank"]: o for o in outs}
+    assert 1 in by_rank and by_rank[1]["learned"] and by_rank[1]["raised"], by_rank.get(1)
+    assert not killed, "a rank was still blocked in a collective when the time limit ended"
+    for r, o in by_rank.items():
+        if r != 1:
+            assert o["raised"] is None          # the others ran the agreed order; whatever they got came from the broken group

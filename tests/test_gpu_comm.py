@@ -42,6 +42,15 @@ if os.environ.get("OCTMAE_SKIP_2RANK_GLOO_TEST") is None and torch.cuda.device_c
          "--master-port", "29619", os.path.join(ROOT, "tests", "dp_worker.py")],
         cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
 
+# ---- bench.py itself with FOUR ranks on the one GPU (gloo): the multi-rank control flow of the script the driver launches on 8 ----
+_CHILD_BENCH4 = None
+if os.environ.get("OCTMAE_SKIP_BENCH4_TEST") is None and torch.cuda.device_count() >= 1:
+    _CHILD_BENCH4 = subprocess.Popen(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+         "--master-port", "29623", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--gloo-one-gpu", "--same-data",
+         "--global-batch", "16", "--micro-batch", "4", "--steps", "2", "--warmup", "2"],
+        cwd=ROOT, env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
 if torch.cuda.is_available():
     from octcubem_amd import comm as ocomm, models_mae, misc, optim as foptim
     from octcubem_amd.parallel import FlatGradReducer
@@ -205,3 +214,27 @@ def test_two_ranks_on_one_gpu_gradients_equal_the_mean_of_the_local_ones():
     assert res["ranks_agree"]
     assert res["cold"] == ["high_res_patch_embed.proj.bias", "high_res_patch_embed.proj.weight"], res["cold"]
     assert res["reducer"]["launched_in_backward"] > 0
+
+
+@pytest.mark.skipif(_CHILD_BENCH4 is None, reason="needs a GPU")
+def test_bench_script_with_four_ranks_prints_one_line_and_ranks_agree():
+    """bench.py as the driver launches it (torch.distributed.run, one process per rank), world size 4, every rank on GPU 0 and
+    the exchange over gloo (--gloo-one-gpu; RCCL refuses several ranks per device): ViT-L, global batch 16 as 4 volumes per rank.
+    Exercises, on hardware, everything of an N-rank run except RCCL itself: rendezvous, the reducer's learning step, the cold-set
+    and launch-order agreements, two frozen-layout steps, the max-over-ranks timing and rank 0's single JSON line.  With
+    --same-data every rank holds the same weights, volumes and masking noise, so the ranks' losses must be BIT-equal after the
+    exchanged optimizer steps."""
+    out, err = _CHILD_BENCH4.communicate(timeout=1500)
+    assert _CHILD_BENCH4.returncode == 0, err.decode(errors="replace")[-4000:]
+    lines = [l for l in out.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines                                  # ONE line on stdout (banners and logs go to stderr)
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 4 and res["config"]["global_batch"] == 16 and res["config"]["micro_batch_per_gpu"] == 4
+    assert res["unit"] == "volumes/s" and res["value"] > 0 and res["scaling"] == "strong"
+    c = res["comm"]
+    assert c["backend"].startswith("torch.distributed gloo") and c["ranks_seen"] == 4 and c["agreed_micro_batch"] == 4
+    lo, hi = c["last_loss_min_max_over_ranks"]
+    assert lo == hi == res["loss"], (lo, hi, res["loss"])
+    red = c["reducer"]
+    assert red["transport"] == "torch.distributed/gloo" and red["launched_in_backward"] > 0
+    assert any(red["cold_chunk"])                                  # high_res_patch_embed: exchanged at begin_backward()
