@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const unsigned m0o = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + OLD + ((buf * 2 + u) * NW + wid) * 1024));
-      lds_dma16(m0o, wsoff + base + (unsigned)tile * WS_TILE + (unsigned)u * WS_SUB, rsW);
+      lds_dma16_ws(m0o, wsoff + base + (unsigned)tile * WS_TILE + (unsigned)u * WS_SUB, rsW);
     }
   };
 
@@ -267,16 +267,25 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
     const unsigned o_imglo = a_imglo, o_imghi = a_imghi, o_old = a_old, o_wsoff = wsoff;
 #define BWD1W_DRAIN_ADDRS \
   [[maybe_unused]] const unsigned a_imglo = opaque(o_imglo), a_imghi = opaque(o_imghi), a_old = opaque(o_old), wsoff = opaque(o_wsoff);
+    // The wait at the top of iteration t retires the vector-memory operations of iteration t - 2 and earlier -- except that
+    // iteration's LAST operation, the write-out store of its sub-step 1: nothing issued behind it is needed yet, and vmcnt
+    // retires in order, so letting that store (HBM write latency under load) stay pending costs no correctness and gives every
+    // store one more iteration to complete (BWD1W_VMWAIT_EXTRA = 1).  t = 1 keeps the plain count: the prologue's last request,
+    // the workspace values of tile 0, is read in that iteration.
+#ifndef BWD1W_VMWAIT_EXTRA
+#define BWD1W_VMWAIT_EXTRA 1
+#endif
+#define BWD1W_WAIT(t_) do { if ((t_) > 1) wait_vm<7 + BWD1W_VMWAIT_EXTRA>(); else wait_vm<7>(); } while (0)
     const int nloop = half_drain ? ntiles - 1 : ntiles;
     for (int t = 0; t < nloop; ++t) {
-      if (t > 0) wait_vm<7>();
+      if (t > 0) BWD1W_WAIT(t);
       BWD1W_TILE_SETUP
 #include "attn_bwd1w_body.inc"
     }
     if (half_drain) {
       {
         const int t = ntiles - 1;
-        wait_vm<7>();
+        BWD1W_WAIT(t);
         BWD1W_TILE_SETUP
 #define BWD1W_ONLY_SUBSTEP0
 #include "attn_bwd1w_body.inc"
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
       }
       {
         const int t = ntiles;
-        wait_vm<7>();
+        BWD1W_WAIT(t);
         BWD1W_TILE_SETUP
         BWD1W_DRAIN_ADDRS
 #define BWD1W_DRAIN_TINY0
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w_kernel(const bf16_t* 
       }
     } else {
       const int t = ntiles;
-      wait_vm<7>();
+      BWD1W_WAIT(t);
       BWD1W_TILE_SETUP
       BWD1W_DRAIN_ADDRS
 #define BWD1W_DRAIN_SLIM0

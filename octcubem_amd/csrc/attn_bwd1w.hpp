@@ -16,6 +16,24 @@ __device__ __forceinline__ void wait_vm() {
 __device__ __forceinline__ void lds_dma16(unsigned m0v, unsigned voff, i32x4_t rsrc) {
   asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc) : "memory", "m0");
 }
+// the workspace traffic (fp32 dQ partial sums, read-modify-written once per key block) with its own cache policy switches:
+// BWD1W_WS_ST_AUX = aux bits of the store (0 default, 2 = nt), -DBWD1W_WS_LD_NT = nt on the LDS-DMA loads of the old values
+#ifndef BWD1W_WS_ST_AUX
+#define BWD1W_WS_ST_AUX 0
+#endif
+// timing-only experiment (-DBWD1W_ST_SMALL): every write-out store lands in the first 64 KB of the (batch, head)'s workspace
+#ifdef BWD1W_ST_SMALL
+#define BWD1W_RVO(x) ((x) & 0xFFFFu)
+#else
+#define BWD1W_RVO(x) (x)
+#endif
+__device__ __forceinline__ void lds_dma16_ws(unsigned m0v, unsigned voff, i32x4_t rsrc) {
+#ifdef BWD1W_WS_LD_NT
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" ::"s"(m0v), "v"(voff), "s"(rsrc) : "memory", "m0");
+#else
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc) : "memory", "m0");
+#endif
+}
 __device__ __forceinline__ void lds_dma4(unsigned m0v, unsigned voff, i32x4_t rsrc) {
   asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc) : "memory", "m0");
 }

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w64_kernel(const bf16_t
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const unsigned m0o = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + OLD + buf * OLD_TILE + (u * NW + wid) * 1024));
-      lds_dma16(m0o, wsoff + base + (unsigned)tile * WS_TILE + (unsigned)(u >> 1) * WS_SUB + (unsigned)(u & 1) * WS_QT, rsW);
+      lds_dma16_ws(m0o, wsoff + base + (unsigned)tile * WS_TILE + (unsigned)(u >> 1) * WS_SUB + (unsigned)(u & 1) * WS_QT, rsW);
     }
   };
 
@@ -303,12 +303,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w64_kernel(const bf16_t
   [[maybe_unused]] const unsigned a_imglo = opaque(o_imglo), a_imghi = opaque(o_imghi), a_old = opaque(o_old), wsoff = opaque(o_wsoff);
     // (here only for lengths whose last tile has no row in its second half -- every length of this model; other lengths drain through
     // two padding iterations in full: a second copy of the drain code costs this kernel register spills)
+    // (as in attn_bwd1w.hip: the two write-out stores that end iteration t - 2 may stay pending at the top of iteration t)
+#ifndef BWD1W_VMWAIT_EXTRA
+#define BWD1W_VMWAIT_EXTRA 2
+#endif
+#define BWD1W_WAIT(t_) do { if ((t_) > 1) wait_vm<13 + BWD1W_VMWAIT_EXTRA>(); else wait_vm<13>(); } while (0)
     const int nloop = half_drain ? ntiles - 1 : ntiles + 1;
     for (int t = 0; t < nloop; ++t) {
 #ifdef BWD1W_STAMP
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sw_[0]));
 #endif
-      if (t > 0) wait_vm<13>();
+      if (t > 0) BWD1W_WAIT(t);
 #ifdef BWD1W_STAMP
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sw_[1]));
       acc_[0][6] += (unsigned)sw_[1] - (unsigned)sw_[0];
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w64_kernel(const bf16_t
     if (half_drain) {
       {
         const int t = ntiles - 1;
-        wait_vm<13>();
+        BWD1W_WAIT(t);
         BWD1W_TILE_SETUP
 #define BWD1W_ONLY_SUBSTEP0
 #include "attn_bwd1w_body_hd64.inc"
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused1w64_kernel(const bf16_t
       }
       {
         const int t = ntiles;
-        wait_vm<13>();
+        BWD1W_WAIT(t);
         BWD1W_TILE_SETUP
         BWD1W_DRAIN_ADDRS
 #define BWD1W_DRAIN_TINY0

@@ -215,7 +215,9 @@ def test_zero_grad_touches_only_its_own_slices_of_the_gradient_arena():
     cfg = O.MAEConfig(input_size=64, in_chans=1, embed_dim=128, depth=2, num_heads=2, decoder_embed_dim=64, decoder_depth=1,
                       decoder_num_heads=2, num_frames=6, t_patch_size=3, pred_t_dim=6, high_res_input_size=128)
     m = build(cfg)
+    m.prepare()                                                      # binds the arena: every param.grad becomes a view of it
     named = [(k, p) for k, p in m.named_parameters() if p.grad is not None]
+    assert len(named) > 40
     for split in ("halves", "interleaved", "small_vs_rest"):
         if split == "halves":
             a = named[:len(named) // 2]; b = named[len(named) // 2:]

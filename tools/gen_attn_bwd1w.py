@@ -183,8 +183,8 @@ def sub_step(s):
                 dqo = "dqB" if s == 0 else "dqA"       # the tile finished in the previous sub-step
                 # element by element: a <4 x float> add becomes v_pk_add_f32, which costs more beside MFMAs than two v_add_f32
                 add("add", f"f32x4 rv; rv[0] = {dqo}[0] + rold[0]; rv[1] = {dqo}[1] + rold[1]; rv[2] = {dqo}[2] + rold[2]; rv[3] = {dqo}[3] + rold[3];", tag="RA0")
-                add("vaddr", f"const unsigned rvo = wsoff + s_redoff{s};", tag="RVO")
-                add("store", "__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rv), rsWs, rvo, 0, 0);", tag="RST")
+                add("vaddr", f"const unsigned rvo = BWD1W_RVO(wsoff + s_redoff{s});", tag="RVO")
+                add("store", "__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rv), rsWs, rvo, 0, BWD1W_WS_ST_AUX);", tag="RST")
             if half == 1 and g < 3:
                 for j in range(4 * g + 4, 4 * g + 8):
                     rd(j)
@@ -297,9 +297,9 @@ def sub_step64(s):
                 for qt in range(2):
                     add("add", f"f32x4 rv{qt}; rv{qt}[0] = {dqo}{qt}[0] + rold{qt}[0]; rv{qt}[1] = {dqo}{qt}[1] + rold{qt}[1]; "
                                f"rv{qt}[2] = {dqo}{qt}[2] + rold{qt}[2]; rv{qt}[3] = {dqo}{qt}[3] + rold{qt}[3];", tag=f"RA{qt}")
-                add("vaddr", f"const unsigned rvo = wsoff + s_redoff{s};", tag="RVO")
-                add("store", "__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rv0), rsWs, rvo, 0, 0);", tag="RST0")
-                add("store", "__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rv1), rsWs, rvo + 4096u, 0, 0);", tag="RST1")
+                add("vaddr", f"const unsigned rvo = BWD1W_RVO(wsoff + s_redoff{s});", tag="RVO")
+                add("store", "__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rv0), rsWs, rvo, 0, BWD1W_WS_ST_AUX);", tag="RST0")
+                add("store", "__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rv1), rsWs, rvo + 4096u, 0, BWD1W_WS_ST_AUX);", tag="RST1")
             if half == 0 and g == 1 and s == 0:
                 add("dma", "issue_tile();", tag="DMA")
         if g == 1:
