@@ -168,3 +168,64 @@ def test_coem_step_with_reducers_exchanges_both_towers():
                 assert hot >= 1 and r.stats["launched_in_backward"] - b0[reds.index(r)] == len(r.bounds)
     finally:
         comm1.destroy()
+
+
+# the reference's shipped model config for BASELINE config 5, values as in
+# retinal-COEM/src/open_clip/model_configs/vit_large_patch16_retFound-vit_large_patch16_OCTCube.json (checkpoint paths dropped:
+# no weights in the image; drop_path 0 and the non-flash semantics for a parity run, as the pins were generated)
+SHIPPED_CFG = {
+    "embed_dim": 512,
+    "vision_cfg": {"image_size": 256, "layers": 24, "width": 1024, "patch_size": 16, "num_heads": 16, "t_patch_size": 3, "in_chans": 1,
+                   "mlp_ratio": 4, "norm_layer_eps": 1e-6, "drop_path_rate": 0.0, "use_flash_attn": True, "attn_drop_rate": 0.0,
+                   "drop_rate": 0.0, "global_pool": True, "model_name": "ViT_ST_nodrop", "model_ckpt": ""},
+    "text_cfg": {"image_size": 224, "layers": 24, "width": 1024, "patch_size": 16, "num_heads": 16, "in_chans": 3, "mlp_ratio": 4,
+                 "norm_layer_eps": 1e-6, "drop_path_rate": 0.0, "use_flash_attn": True, "dropout": 0.5, "attn_drop_rate": 0.0,
+                 "drop_rate": 0.0, "global_pool": True, "vit_model_name": "ViT_flash_attn", "model_ckpt": ""}}
+
+
+def test_full_size_config5_step_vs_reference_pins(golden_dir):
+    """BASELINE config 5 at FULL size on one GPU: the shipped tower config (ViT-L ST tower on (2,1,60,256,256), N = 5121 tokens,
+    + ViT-L 2-D tower on (2,3,224,224), embed 512) through coem.create_model_from_config, one contrastive step, against pins
+    produced by the reference's own tower classes and its own ClipLoss (oracle/gen_golden_coem_full.py: features, loss,
+    logit-scale gradient, gradient norm per tower and per tensor, strided gradient samples).
+    retinal-COEM/src/open_clip/model.py:635-682, loss.py:21-65.  Bounds = measured x ~1.5 (conftest.parity ledger)."""
+    import json, os
+    from tests.conftest import parity
+    z = np.load(os.path.join(golden_dir, "coem_l_pins.npz"))
+    model = coem.create_model_from_config(json.loads(json.dumps(SHIPPED_CFG)), flash_semantics=False)
+    PA = V.init_from_shapes(V.vit_st_param_shapes(V.ViTSTConfig(**json.loads(str(z["cfg_a"])))), seed=int(z["seed_a"]))
+    PB = V.init_from_shapes(V.vit2d_param_shapes(V.ViT2DConfig(**json.loads(str(z["cfg_b"])))), seed=int(z["seed_b"]))
+    model.visual.load_state_dict(PA, strict=True); model.text.load_state_dict(PB, strict=True)
+    model = model.to(DEV).eval()                       # eval: dropout before the 2-D tower's head off, as in the pins
+    vol = torch.rand(2, 1, 60, 256, 256, generator=torch.Generator().manual_seed(int(z["vol_seed"]))).to(DEV)
+    ir = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(int(z["ir_seed"]))).to(DEV)
+    fa, fb, ls = model(vol, ir)
+    loss = coem.ClipLoss()(fa, fb, ls)
+    loss.backward()
+    torch.cuda.synchronize()
+    parity("coem_l/feat_a", rel(fa, z["feat_a"]), 1.5e-2)
+    parity("coem_l/feat_b", rel(fb, z["feat_b"]), 1.5e-2)
+    parity("coem_l/loss", abs(float(loss) - float(z["loss"])) / abs(float(z["loss"])), 5e-3)
+    parity("coem_l/logit_scale_grad", abs(float(model.logit_scale.grad) - float(z["logit_scale_grad"])) / (abs(float(z["logit_scale_grad"])) + 1e-3), 5e-2)
+    for tag, tower in (("a", model.visual), ("b", model.text)):
+        names = json.loads(str(z[f"grad_names_{tag}"]))
+        norms = dict(zip(names, z[f"grad_norms_{tag}"]))
+        grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in tower.named_parameters()}
+        assert set(grads) == set(names)
+        tot = float(torch.sqrt(sum(g.double().pow(2).sum() for g in grads.values())))
+        ref_tot = float(z[f"tower_grad_norm_{tag}"])
+        parity(f"coem_l/tower_grad_norm_{tag}", abs(tot - ref_tot) / ref_tot, 2e-2)
+        worst = 0.0
+        for k in names:
+            if norms[k] >= 1e-2 * ref_tot:
+                worst = max(worst, abs(float(grads[k].double().norm()) - norms[k]) / norms[k])
+        parity(f"coem_l/worst_tensor_norm_{tag}", worst, 5e-2)
+        errs = []
+        for key in z.files:
+            if key.startswith(f"gsample_{tag}/"):
+                k = key.split("/", 1)[1]
+                step = int(z[f"gstep_{tag}/{k}"])
+                mine = grads[k].flatten()[::step][:len(z[key])]
+                if norms[k] >= 1e-2 * ref_tot:
+                    errs.append(rel(mine, z[key]))
+        parity(f"coem_l/grad_samples_max_{tag}", max(errs), 8e-2)

@@ -25,6 +25,8 @@ for p in paths:
 g = torch.Generator(device="cuda").manual_seed(0)
 qkv = torch.randn(B * N, 3 * H * HD, device="cuda", generator=g).to(torch.bfloat16)
 do = torch.randn(B * N, H * HD, device="cuda", generator=g).to(torch.bfloat16)
+if os.environ.get("ZERO") == "1":      # all-zero operands: the same instruction stream at minimal switching power (DVFS probe)
+    qkv.zero_(); do.zero_()
 scale = HD ** -0.5
 o, lse = ops.attn_fwd(qkv, B, N, H, HD, scale)
 kib = libs[0].octmae_attn_bwd_fused_ws_kib(B, N, H, HD)
