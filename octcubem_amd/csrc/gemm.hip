@@ -360,10 +360,14 @@ constexpr unsigned EPI_OOB = 0x7ffffff0u;
 #define EPI_STORE_AUX 3   // sc0 nt: streaming stores (outputs are >= 100 MB and not re-read before they leave the L2); measured -5..6 % on the bf16 / GELU forwards
 #endif   // byte offset past any num_records above: masks a lane whose columns are >= NA
 
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&acc)[4][2], int a_base, int b_base, int lane,
+// Q = false: acc is f32x16[4][2], the 32x32 C layout above.  Q = true: acc is f32x4[8][4], 16 x 16 tiles (a-tile ti, b-tile tj)
+// of v_mfma_f32_16x16x32_bf16: register e of lane (c16 = lane & 15, q4 = lane >> 4) is X[a_base + 16 ti + 4 q4 + e][b_base + 16 tj + c16].
+// Either way a lane holds quads of 4 consecutive a of one output row b, so only the WRITE side of the transpose differs.
+template <int EPI, bool Q = false, class AccT>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, AccT& acc, int a_base, int b_base, int lane,
                                                   char* wl) {
   const int r = lane & 31, h = lane >> 5;
+  [[maybe_unused]] const int c16 = lane & 15, q4 = lane >> 4;
   const int rrow = lane >> 4, rc = lane & 15;   // read side: 16 lanes per 256-B row, 4 rows per instruction
   if (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU) {
     // bf16 image [64 b][128 a].  EPI_DGELU multiplies by gelu'(pre) on the read side: the product of the bf16-rounded
@@ -388,30 +392,44 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
 #pragma unroll
       for (int g = 0; g < 4; ++g) bias_q[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (EPI != EPI_DGELU && p.bias != nullptr) {
+      if constexpr (!Q) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          bias_q[i][g] = *reinterpret_cast<const f32x4*>(p.bias + min(a_base + i * 32 + 8 * g + 4 * h, p.NA - 4));
+          for (int g = 0; g < 4; ++g)
+            bias_q[i][g] = *reinterpret_cast<const f32x4*>(p.bias + min(a_base + i * 32 + 8 * g + 4 * h, p.NA - 4));
+      } else {
+#pragma unroll
+        for (int ti = 0; ti < 8; ++ti)
+          bias_q[ti >> 2][ti & 3] = *reinterpret_cast<const f32x4*>(p.bias + min(a_base + ti * 16 + 4 * q4, p.NA - 4));
+      }
     }
 #pragma unroll
     for (int pass = 0; pass < (EPI == EPI_GELU ? 2 : 1); ++pass) {
+      auto put = [&](f32x4 v, const f32x4 bv, int row, int chunk, int half8) {
+        u32x2 w = {pack2bf(v[0] + bv[0], v[1] + bv[1]), pack2bf(v[2] + bv[2], v[3] + bv[3])};
+        if (pass == 1) {   // activation of the bf16-ROUNDED pre-activation (what backward differentiates)
+          const f32x2 y0 = gelu_f2(f32x2{bflo(w[0]), bfhi(w[0])}), y1 = gelu_f2(f32x2{bflo(w[1]), bfhi(w[1])});
+          w = u32x2{pack2bf(y0[0], y0[1]), pack2bf(y1[0], y1[1])};
+        }
+        *reinterpret_cast<u32x2*>(wl + epi_off(row, chunk) + 8 * half8) = w;
+      };
+      if constexpr (!Q) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 bv = bias_q[i][g];
+          for (int g = 0; g < 4; ++g) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            u32x2 w = {pack2bf(acc[i][j][4 * g] + bv[0], acc[i][j][4 * g + 1] + bv[1]),
-                       pack2bf(acc[i][j][4 * g + 2] + bv[2], acc[i][j][4 * g + 3] + bv[3])};
-            if (pass == 1) {   // activation of the bf16-ROUNDED pre-activation (what backward differentiates)
-              const f32x2 y0 = gelu_f2(f32x2{bflo(w[0]), bfhi(w[0])}), y1 = gelu_f2(f32x2{bflo(w[1]), bfhi(w[1])});
-              w = u32x2{pack2bf(y0[0], y0[1]), pack2bf(y1[0], y1[1])};
-            }
-            const int row = j * 32 + r;
-            *reinterpret_cast<u32x2*>(wl + epi_off(row, 4 * i + g) + 8 * h) = w;
+            for (int j = 0; j < 2; ++j)
+              put(f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]}, bias_q[i][g], j * 32 + r,
+                  4 * i + g, h);
           }
+        }
+      } else {
+#pragma unroll
+        for (int ti = 0; ti < 8; ++ti) {
+#pragma unroll
+          for (int tj = 0; tj < 4; ++tj) put(acc[ti][tj], bias_q[ti >> 2][ti & 3], tj * 16 + c16, 2 * ti + (q4 >> 1), q4 & 1);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -499,17 +517,26 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
     }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+      if constexpr (!Q) {
 #pragma unroll
-      for (int i2 = 0; i2 < 2; ++i2) {
-        const int i = half * 2 + i2;
+        for (int i2 = 0; i2 < 2; ++i2) {
+          const int i = half * 2 + i2;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+          for (int g = 0; g < 4; ++g) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            f32x4 w = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-            const int row = j * 32 + r;
-            *reinterpret_cast<f32x4*>(wl + epi_off(row, i2 * 8 + 2 * g + h)) = w;
+            for (int j = 0; j < 2; ++j) {
+              f32x4 w = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+              const int row = j * 32 + r;
+              *reinterpret_cast<f32x4*>(wl + epi_off(row, i2 * 8 + 2 * g + h)) = w;
+            }
           }
+        }
+      } else {
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) {
+#pragma unroll
+          for (int tj = 0; tj < 4; ++tj)
+            *reinterpret_cast<f32x4*>(wl + epi_off(tj * 16 + c16, t2 * 4 + q4)) = acc[half * 4 + t2][tj];
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -861,8 +888,211 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const GemmParams p) {
   }
 }
 
+
+// =====================================================================================================
+// gemm256q_kernel: the phased main loop above on v_mfma_f32_16x16x32_bf16 (round 4).  Same tile (256 x 256 x 64), same staging,
+// same phases and barriers, same LDS-DMA ring; a phase is 16 MFMAs of 16 cycles instead of 8 of 32.  Why: these kernels are
+// POWER-limited, not issue-limited -- the same binary runs 19-26 % faster on all-zero operands (profiles/r04_dvfs_probe.txt) --
+// and the chip holds a higher clock on the 16x16x32 shape (MI355X_MICROARCH.md, DVFS give-back item 7; tools/ubench/
+// bwd_block_shapes.hip measured +14 % clock for +6 % cycles): per multiply-accumulate it moves 0.25 B of operands and 0.25 B of
+// accumulator through the register file against 0.125 B + 0.5 B for 32x32x16.
+//   * A operand (lane l: row l & 15, k = 8 (l >> 4) .. + 7 of a 32-deep k-step): one ds_read_b128 per 16 rows and k-step from the
+//     k-contiguous image (conflict-free on the shipped swizzle: tools/lds_bank_check.py), two transposed reads from the
+//     k-strided image, whose chunk swizzle gains the (kr >> 2) & 3 term of cdna_hip_programming.md T10 image (b): the four
+//     lane groups of a wave read the SAME 16 columns of k rows 8 apart, 2-way conflicts on the shipped swizzle;
+//   * accumulators: f32x4 acc[8][4] (a-tile, b-tile); the epilogue is gemm_epilogue_lds<EPI, true> (write side of the transpose).
+// Built for the forward and dgrad kinds (OUT_AB = false, NA % 8 == 0); weight gradients stay on gemm256p_kernel (their fp32
+// atomics want 128-B row segments per register: 32 consecutive b, the 32x32 C layout).
+// =====================================================================================================
+__device__ __forceinline__ int ksQ_off(int kr, int c) { return kr * 256 + ((c ^ (((kr & 3) << 2) | ((kr >> 2) & 3))) << 4); }  // [64 k][128 rows]
+
+// fragment of 16 rows starting at in-half row rb for the 32-deep k-step s2 (0 / 1) of one 16 KiB half-image
+template <bool KS>
+__device__ __forceinline__ bf16x8 read_fragQ(const char* lds, int rb, int s2, int lane) {
+  if (!KS) {
+    const int r = rb + (lane & 15), c = 4 * s2 + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(lds + kcH_off(r, c));
+  } else {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int c = (rb >> 3) + (pp >> 1);
+    const int kr0 = 32 * s2 + 8 * g + q;
+    const bf16x4 lo = lds_tr_read(lds + ksQ_off(kr0, c) + (pp & 1) * 8);
+    const bf16x4 hi = lds_tr_read(lds + ksQ_off(kr0 + 4, c) + (pp & 1) * 8);
+    return cat4(lo, hi);
+  }
+}
+
+__device__ __forceinline__ f32x4 mfma16q(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+template <bool A_KS, bool B_KS, int EPI>
+__global__ __launch_bounds__(512, 1) void gemm256q_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [stage 2][operand 2][half 2] x 16 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wa = wid >> 2, wb = wid & 3;          // wa = 1: the late group (waves 4-7)
+
+  const int nt = p.tiles_a * p.tiles_b;
+  const int t = xcd_remap(blockIdx.x, nt);
+  int ta, tb;
+  tile_coord(p, t, ta, tb);
+  const int a0 = ta * T2, b0 = tb * T2;
+  const int nk = p.ktiles;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  {
+    const unsigned a_bytes = (unsigned)((size_t)(A_KS ? p.K : p.NA) * p.lda * 2);
+    const unsigned b_bytes = (unsigned)((size_t)(B_KS ? p.K : p.NB) * p.ldb * 2);
+    const unsigned long long pa = (unsigned long long)p.A, pb = (unsigned long long)p.B;
+    const gi32x4 ra = {(int)(unsigned)pa, (int)(unsigned)(pa >> 32), (int)a_bytes, 0x00020000};
+    const gi32x4 rb = {(int)(unsigned)pb, (int)(unsigned)(pb >> 32), (int)b_bytes, 0x00020000};
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    // per-lane source offsets of this wave's two 1-KiB pieces of each half-image (k-tile 0), and the k-tile stride
+    unsigned va[2][2], vb[2][2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int j = 2 * wid + n;
+        if (!A_KS) {
+          const int r = 8 * j + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+          va[hf][n] = (unsigned)(((size_t)(a0 + hf * 128 + r) * p.lda + c * 8) * 2);
+        } else {
+          const int kr = 4 * j + (lane >> 4), c = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
+          va[hf][n] = (unsigned)(((size_t)kr * p.lda + a0 + hf * 128 + c * 8) * 2);
+        }
+        if (!B_KS) {
+          const int r = 8 * j + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+          vb[hf][n] = (unsigned)(((size_t)(b0 + hf * 128 + r) * p.ldb + c * 8) * 2);
+        } else {
+          const int kr = 4 * j + (lane >> 4), c = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
+          vb[hf][n] = (unsigned)(((size_t)kr * p.ldb + b0 + hf * 128 + c * 8) * 2);
+        }
+      }
+    const unsigned ka = (unsigned)(A_KS ? (size_t)TK * p.lda * 2 : (size_t)TK * 2);
+    const unsigned kb = (unsigned)(B_KS ? (size_t)TK * p.ldb * 2 : (size_t)TK * 2);
+    auto stage = [&](int op, int kt, int buf) {            // both halves of operand `op` of k-tile kt -> stage buf (4 loads)
+      const unsigned base = lds0 + (unsigned)(buf * 65536 + op * 32768 + 2 * wid * 1024);
+      const unsigned so = (unsigned)kt * (op ? kb : ka);
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          glds16(op ? rb : ra, base + (unsigned)(hf * 16384 + n * 1024), op ? vb[hf][n] : va[hf][n], so);
+    };
+    // prologue: B(0), A(0), B(1) -- the order the loop keeps (B a k-tile ahead of A)
+    stage(1, 0, 0);
+    stage(0, 0, 0);
+    stage(1, 1, 1);
+    __builtin_amdgcn_s_waitcnt(0x0F74);       // vmcnt(4) (lgkmcnt/expcnt untouched): A(0), B(0) have landed
+    __builtin_amdgcn_s_barrier();
+    if (wa) __builtin_amdgcn_s_barrier();     // the late group starts one barrier behind
+
+    const int rowB = (wb & 1) * 64;           // this wave's 64 b-rows inside its B half
+    bf16x8 fa[4][2], fb[4][2];
+    for (int it = 0; it < nk; ++it) {
+      const int buf = it & 1;
+      const char* cA = smem + buf * 65536 + wa * 16384;                    // my A half: rows wa*128 ..
+      const char* cB = smem + buf * 65536 + 32768 + (wb >> 1) * 16384;     // my B half
+      // ---- phase 1: a 0..63 x b 0..31
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) fb[tj][s] = read_fragQ<B_KS>(cB, rowB + 16 * tj, s, lane);
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) fa[ti][s] = read_fragQ<A_KS>(cA, 16 * ti, s, lane);
+      stage(0, it + 1, buf ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = mfma16q(fa[ti][s], fb[tj][s], acc[ti][tj]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // ---- phase 2: a 0..63 x b 32..63
+#pragma unroll
+      for (int tj = 2; tj < 4; ++tj)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) fb[tj][s] = read_fragQ<B_KS>(cB, rowB + 16 * tj, s, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+          for (int tj = 2; tj < 4; ++tj) acc[ti][tj] = mfma16q(fa[ti][s], fb[tj][s], acc[ti][tj]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // ---- phase 3: a 64..127 x b 32..63
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) fa[ti][s] = read_fragQ<A_KS>(cA, 64 + 16 * ti, s, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+          for (int tj = 2; tj < 4; ++tj) acc[4 + ti][tj] = mfma16q(fa[ti][s], fb[tj][s], acc[4 + ti][tj]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // ---- phase 4: a 64..127 x b 0..31
+      stage(1, it + 2, buf);
+      __builtin_amdgcn_s_waitcnt(0x0F74);     // vmcnt(4): everything but the B halves just issued -- A(it+1), B(it+1) landed
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < 2; ++tj) acc[4 + ti][tj] = mfma16q(fa[ti][s], fb[tj][s], acc[4 + ti][tj]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    }
+    if (!wa) __builtin_amdgcn_s_barrier();    // the early group waits for the late one
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the trailing (unused) prefetches must not land in the epilogue's LDS
+    __builtin_amdgcn_s_barrier();
+  }
+  gemm_epilogue_lds<EPI, true>(p, acc, a0 + wa * 128, b0 + wb * 64, lane, smem + wid * 16384);
+}
+
+// 16x16x32 MFMAs in the 256-tile forward / dgrad kernels (octmae_set_option "gemm_mfma16"; bit 11 of the epilogue argument forces
+// the 32x32x16 kernel for tests and A/B runs)
+std::atomic<int> g_gemm_mfma16{1};
+
 template <bool A_KS, bool B_KS, int EPI, bool OUT_AB>
-static int launch256(const GemmParams& p, int splitk, hipStream_t st, bool phased) {
+static int launch256(const GemmParams& p, int splitk, hipStream_t st, bool phased, bool mfma16) {
+  if constexpr (!OUT_AB && !(A_KS && B_KS)) {
+    if (mfma16 && phased && splitk == 1 && (p.NA & 7) == 0) {
+      auto kq = gemm256q_kernel<A_KS, B_KS, EPI>;
+      static DynLdsOnce onceq;
+      if (int rc = onceq.ensure(reinterpret_cast<const void*>(kq), 4 * TILE2_BYTES)) return rc;
+      hipLaunchKernelGGL(kq, dim3(p.tiles_a * p.tiles_b, 1, 1), dim3(512), 4 * TILE2_BYTES, st, p);
+      OCTMAE_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   auto kern = phased ? gemm256p_kernel<A_KS, B_KS, EPI, OUT_AB> : gemm256_kernel<A_KS, B_KS, EPI, OUT_AB>;
   static DynLdsOnce once[2];
   if (int rc = once[phased].ensure(reinterpret_cast<const void*>(kern), 4 * TILE2_BYTES)) return rc;
@@ -901,6 +1131,7 @@ static int gemm_impl(const void* A, const void* B, void* C, void* C2, const floa
   // epilogue work: qkv -4 %, proj -11 %, fc2 -8 %, fc1 + GELU -1.5 %, decoder fc1 + GELU +0.6 % -- in round 1 the two-stage loop
   // had still been 12 % faster at K = 1024).  bit 9 forces the two-stage loop, bit 10 the phased one.
   const bool phased = ((epilogue >> 10) & 1) ? true : ((epilogue >> 9) & 1) ? false : true;
+  const bool mfma16 = ((epilogue >> 11) & 1) ? false : (g_gemm_mfma16.load(std::memory_order_relaxed) != 0);
   epilogue &= 0xff;
   OCTMAE_CHECK_ARG(A && B && C);
   OCTMAE_CHECK_ARG(NA > 0 && NB > 0 && K > 0);
@@ -967,7 +1198,7 @@ static int gemm_impl(const void* A, const void* B, void* C, void* C2, const floa
   if (epilogue == EPI_DGELU && p.C2 != nullptr && colsum_ws != nullptr) { p.C2 = colsum_ws; p.ldc2 = NA; }
 #define OCTMAE_GEMM_CASE(AKS, BKS, E, AB)                                  \
   if (a_kstrided == AKS && b_kstrided == BKS && epilogue == E) {           \
-    int rc_ = big ? launch256<AKS, BKS, E, AB>(p, splitk, st, phased) : launch<AKS, BKS, E, AB>(p, splitk, st);          \
+    int rc_ = big ? launch256<AKS, BKS, E, AB>(p, splitk, st, phased, mfma16) : launch<AKS, BKS, E, AB>(p, splitk, st);  \
     if (rc_ == 0 && E == EPI_DGELU && dgelu_colsum != nullptr && p.C2 == nullptr)                                       \
       rc_ = octmae_colsum_accum(C, 1, dgelu_colsum, NB, NA, ldc, stream);                                                \
     if (rc_ == 0 && E == EPI_DGELU && dgelu_colsum != nullptr && p.ldc2 > 0)                                             \
@@ -1005,7 +1236,7 @@ extern "C" int octmae_linear_resid_rowscale(const void* W, const void* X, float*
                                             const float* rowscale, int rows_per_scale, int N, int M, int K, int ldw, int ldx,
                                             int ldout, int ldres, int small_tile, void* stream) {
   OCTMAE_CHECK_ARG(rowscale != nullptr && rows_per_scale > 0);
-  return gemm_impl(W, X, out, nullptr, bias, res, N, M, K, ldw, ldx, ldout, ldres, 0, 0, EPI_RESID | (small_tile & 0x700), 1,
+  return gemm_impl(W, X, out, nullptr, bias, res, N, M, K, ldw, ldx, ldout, ldres, 0, 0, EPI_RESID | (small_tile & 0xF00), 1,
                    stream, rowscale, rows_per_scale);
 }
 
@@ -1014,6 +1245,6 @@ extern "C" int octmae_dgelu_colsum_ws_rows(int M) { return M > 0 ? 4 * ((M + T2 
 extern "C" int octmae_linear_dgrad_dgelu(const void* W, const void* dY, void* dX, const void* pre, float* ws, float* bias_grad,
                                          int M, int N, int K, int ldw, int ldy, int ldx, int ldpre, int small_tile, void* stream) {
   OCTMAE_CHECK_ARG(bias_grad == nullptr || ws != nullptr);
-  return gemm_impl(W, dY, dX, bias_grad, nullptr, pre, K, M, N, ldw, ldy, ldx, ldpre, 1, 0, EPI_DGELU | (small_tile & 0x700), 1, stream, nullptr, 1,
+  return gemm_impl(W, dY, dX, bias_grad, nullptr, pre, K, M, N, ldw, ldy, ldx, ldpre, 1, 0, EPI_DGELU | (small_tile & 0xF00), 1, stream, nullptr, 1,
                    bias_grad != nullptr ? ws : nullptr);
 }
