@@ -129,6 +129,11 @@ def main():
     ap.add_argument("--gloo-one-gpu", action="store_true",
                     help="diagnostic: every rank on GPU 0, exchange over gloo -- exercises the multi-rank control flow of this script on "
                          "a one-GPU box (RCCL refuses two ranks on one device); the number it prints is not a benchmark")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=INT",
+                    help="kernel-selection switches for same-box A/B runs of the WHOLE step: octmae_set_option keys (attn_bwd_hd32_form, "
+                         "attn_bwd_hd64_form, attn_bwd_tail_fused, gemm_mfma16) or ops.<NAME> flags (ops.FORCE_TWO_STAGE=1, "
+                         "ops.ATTN_BWD_FUSED32=0, ...); repeatable.  Isolated kernel A/Bs do not always carry over to the step "
+                         "(DESIGN.md section 5, round 4), so defaults are decided here")
     ap.add_argument("--same-data", action="store_true",
                     help="diagnostic: every rank draws the SAME volumes (seed without the rank) -- with identical weights and masking "
                          "noise the ranks' losses must then be bit-equal (comm.last_loss_min_max_over_ranks)")
@@ -153,6 +158,15 @@ def main():
     use_dist = world > 1 or args.force_reducer
     from octcubem_amd import models_mae, misc, ops, optim as foptim, comm as ocomm
     from octcubem_amd.parallel import FlatGradReducer
+    for kv in args.set:
+        k, v = kv.split("=")
+        if k.startswith("ops.ATTN_BWD_FUSED"):
+            ops.ATTN_BWD_FUSED[int(k[len("ops.ATTN_BWD_FUSED"):])] = bool(int(v))
+        elif k.startswith("ops."):
+            assert hasattr(ops, k[4:]), k
+            setattr(ops, k[4:], bool(int(v)))
+        else:
+            ops.set_option(k, int(v))
     comm = None
     comm_kind = None
     if use_dist:
@@ -328,7 +342,7 @@ def main():
                                    "mask_ratio 0.75, decoder 512x8x16", "global_batch": args.global_batch,
                        "micro_batch_per_gpu": mb, "accum_steps": accum, "tokens_enc_dec": [1281, 5121],
                        "parallelism": f"dp{world}"},
-            "loss": loss_value,
+            "loss": loss_value, "switches": args.set,
             "model_tflops_per_s": vps * 3 * FWD_GFLOP_PER_VOLUME / 1e3,
             "mfu_vs_dense_bf16_peak": vps * 3 * FWD_GFLOP_PER_VOLUME / 1e3 / (PEAK_BF16_TFLOPS * world),
         }

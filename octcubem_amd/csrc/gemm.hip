@@ -1079,7 +1079,10 @@ __global__ __launch_bounds__(512, 1) void gemm256q_kernel(const GemmParams p) {
 
 // 16x16x32 MFMAs in the 256-tile forward / dgrad kernels (octmae_set_option "gemm_mfma16"; bit 11 of the epilogue argument forces
 // the 32x32x16 kernel for tests and A/B runs)
-std::atomic<int> g_gemm_mfma16{1};
+// Default OFF: same-process A/B of the kernels alone (tools/gemm_mfma_shape_ab.py) has the 16x16x32 form 2-5 % faster on every
+// shape, but in the training step on the same box (bench.py --set gemm_mfma16=1 vs 0, three alternations) it is no faster
+// (167.5 vs 167.7 volumes/s; dgrad +3.7 % slower, forward -1 %): profiles/r04_gemm_mfma16_ab.txt.
+std::atomic<int> g_gemm_mfma16{0};
 
 template <bool A_KS, bool B_KS, int EPI, bool OUT_AB>
 static int launch256(const GemmParams& p, int splitk, hipStream_t st, bool phased, bool mfma16) {
@@ -1131,7 +1134,8 @@ static int gemm_impl(const void* A, const void* B, void* C, void* C2, const floa
   // epilogue work: qkv -4 %, proj -11 %, fc2 -8 %, fc1 + GELU -1.5 %, decoder fc1 + GELU +0.6 % -- in round 1 the two-stage loop
   // had still been 12 % faster at K = 1024).  bit 9 forces the two-stage loop, bit 10 the phased one.
   const bool phased = ((epilogue >> 10) & 1) ? true : ((epilogue >> 9) & 1) ? false : true;
-  const bool mfma16 = ((epilogue >> 11) & 1) ? false : (g_gemm_mfma16.load(std::memory_order_relaxed) != 0);
+  static const int env16 = getenv("OCTMAE_GEMM_MFMA16") ? atoi(getenv("OCTMAE_GEMM_MFMA16")) : -1;      // same-box A/B of whole steps
+  const bool mfma16 = ((epilogue >> 11) & 1) ? false : env16 >= 0 ? env16 != 0 : (g_gemm_mfma16.load(std::memory_order_relaxed) != 0);
   epilogue &= 0xff;
   OCTMAE_CHECK_ARG(A && B && C);
   OCTMAE_CHECK_ARG(NA > 0 && NB > 0 && K > 0);

@@ -172,7 +172,7 @@ _GEMM_KIND = {(0, 0): "gemm_fwd", (1, 0): "gemm_dgrad", (1, 1): "gemm_wgrad"}
 FORCE_SMALL_TILE = False    # tests: route every GEMM through the 128-tile register-staged kernel
 FORCE_TWO_STAGE = False     # tests / A-B: the un-phased two-stage main loop of the 256-tile kernel
 FORCE_PHASED = False        # tests / A-B: the phased main loop also where the two-stage one is the default
-FORCE_MFMA32 = False        # tests / A-B: the 32x32x16 MFMA kernel where the 16x16x32 one (gemm256q_kernel) is the default
+FORCE_MFMA32 = False        # tests / A-B: never the 16x16x32 kernel (gemm256q_kernel; selected by set_option("gemm_mfma16", 1))
 
 
 def _variant_bits():
@@ -329,7 +329,7 @@ ATTN_BWD_FUSED = {32: True, 64: True}
 def set_option(key: str, value: int) -> int:
     """octmae_set_option: kernel-selection switch for A/B measurements and tests ("attn_bwd_hd32_form" / "attn_bwd_hd64_form":
     1 = one wave per SIMD (default), 0 = the two-waves-per-SIMD kernel; "gemm_mfma16": 1 = 16x16x32 MFMAs in the 256-tile
-    forward / dgrad GEMMs (default), 0 = 32x32x16).  Returns the previous value."""
+    forward / dgrad GEMMs, 0 = 32x32x16 (default: no faster in the step).  Returns the previous value."""
     prev = load().octmae_set_option(key.encode(), int(value))
     if prev < 0:
         raise RuntimeError(f"octmae_set_option: unknown key {key!r}")

@@ -77,20 +77,20 @@ GEMM_SHAPES = [(128, 128, 64), (256, 384, 128), (200, 136, 72), (1281, 384, 128)
                (600, 4096, 256), (700, 512, 4096)]      # 16 column tiles, K <= 1024: the column-grouped tile order (forward / dgrad)
 
 
-@pytest.fixture(params=["auto", "tile128", "twostage", "phased", "mfma32"])
+@pytest.fixture(params=["auto", "tile128", "twostage", "phased", "mfma16"])
 def tile_variant(request):
-    """Every GEMM problem runs through the automatic choice (256-tile LDS-DMA kernel, phased main loop, 16x16x32 MFMAs for the
-    forward / dgrad kinds when it fits), through the 128-tile register-staged kernel, through both main loops of the 256-tile
-    kernel (two-stage, phased) and through the phased loop on 32x32x16 MFMAs ("mfma32": gemm256p_kernel for every kind)."""
+    """Every GEMM problem runs through the automatic choice (256-tile LDS-DMA kernel with the phased main loop when it fits),
+    through the 128-tile register-staged kernel, through both main loops of the 256-tile kernel (two-stage, phased) and
+    through the phased loop on 16x16x32 MFMAs ("mfma16": gemm256q_kernel for the forward / dgrad kinds)."""
     ops.FORCE_SMALL_TILE = request.param == "tile128"
     ops.FORCE_TWO_STAGE = request.param == "twostage"
     ops.FORCE_PHASED = request.param == "phased"
-    ops.FORCE_MFMA32 = request.param == "mfma32"
+    prev = ops.set_option("gemm_mfma16", 1 if request.param == "mfma16" else 0)
     yield request.param
     ops.FORCE_SMALL_TILE = False
     ops.FORCE_TWO_STAGE = False
     ops.FORCE_PHASED = False
-    ops.FORCE_MFMA32 = False
+    ops.set_option("gemm_mfma16", prev)
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)

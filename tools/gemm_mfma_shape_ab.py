@@ -39,9 +39,9 @@ for name, lname, M, N, K, mode in cases:
         ts = {0: [], 1: []}
         for r in range(R):
             for m32 in (1, 0):
-                ops.FORCE_MFMA32 = bool(m32)
+                ops.set_option("gemm_mfma16", 0 if m32 else 1)
                 ts[m32].append(t(fn))
-        ops.FORCE_MFMA32 = False
+        ops.set_option("gemm_mfma16", 0)
         a, q = statistics.median(ts[1]), statistics.median(ts[0])
         # calls per step at global batch 256 = 2 micro-batches x layers
         calls = (24 if name == "enc" else 8) * 2
