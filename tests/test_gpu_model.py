@@ -182,9 +182,9 @@ def test_train_step_matches_oracle_adamw():
             # sensitivity of a two-step trajectory to sign flips (which moved from 8.7e-4 to 2.1e-3 when the GELU fits changed)
             # -- and, beside it, the original two-step trajectory check: the oracle's own step-1 parameters (Pt), bound stated.
             loss_t, _, _, _, Gt = O.forward_backward(Pt, imgs, cfg, 0.75, noise)
-            parity("train_step/loss2_trajectory", abs(float(loss) - float(loss_t)) / float(loss_t), 3.2e-3)   # measured 2.1e-3 (r03)
+            parity("train_step/loss2_trajectory", abs(float(loss) - float(loss_t)) / float(loss_t), 3e-4)     # measured 8.4e-5 (r04)
             parity("train_step/grad_norm2_trajectory",
-                   abs(float(norm) - float(O.grad_norm(Gt.values()))) / float(O.grad_norm(Gt.values())), 1e-2)
+                   abs(float(norm) - float(O.grad_norm(Gt.values()))) / float(O.grad_norm(Gt.values())), 3.5e-3)      # measured 2.1e-3
             # parameters after step 1: every element moved by ~lr (Adam), the two trajectories may differ by 2 lr where a
             # gradient below the bf16 noise floor changed sign, never by more
             for k in Pt:
