@@ -89,44 +89,67 @@ _LAUNCH_GROUP = {"attn_bwd_fused_hd32": ["attn_rowconst_pad_kernel<32>", "attn_b
 
 
 class BoardSampler:
-    """Board power and shader clock during the timed region, sampled from a side thread with `rocm-smi --json` (read-only; works
-    as an ordinary user).  The MFMA kernels of this step run AT the package power cap (1400 W) with the clock pulled down to
-    1.65-1.95 GHz -- the same binaries run 19-26 % faster on all-zero operands at 2.4 GHz and 1065-1235 W (tools/power_probe.py,
-    profiles/r04_power_probe.txt) -- so the sustainable dense-bf16 rate of the part on real data is ~1.1-1.3 PFLOP/s, not the
-    nominal 2.5: the line reports what the board did while the number was measured."""
+    """Board power and shader clock during the timed region, read from the amdgpu hwmon files in sysfs by a side thread (plain
+    file reads: no child process is started after the GPU has been initialised).  The MFMA kernels of this step run AT the package
+    power cap (1400 W) with the clock pulled down to 1.65-1.95 GHz -- the same binaries run 19-26 % faster on all-zero operands at
+    2.4 GHz and 1065-1235 W (tools/power_probe.py, profiles/r04_power_probe.txt) -- so the sustainable dense-bf16 rate of the part
+    on real data is ~1.1-1.3 PFLOP/s, not the nominal 2.5: the line reports what the board did while the number was measured."""
 
-    def __init__(self, period=0.5):
+    def __init__(self, device_index=0, period=0.25):
+        import glob
         import threading
-        self.period, self.samples, self._stop = period, [], False
+        self.period, self._stop = period, False
+        self.cards = {}            # hwmon dir -> [(power W, sclk MHz)]
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            want = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            if os.path.exists(os.path.join(h, "power1_input")) and os.path.exists(os.path.join(h, "freq1_input")):
+                pci = os.path.basename(os.path.realpath(os.path.join(h, "..", "..")))
+                self.cards[h] = {"pci": pci, "s": []}
+        match = [h for h, c in self.cards.items() if want is not None and c["pci"] == want]
+        if match:                  # the card HIP device `device_index` is; otherwise every card is sampled and the busiest one reported
+            self.cards = {match[0]: self.cards[match[0]]}
+        self.matched = bool(match)
         self._t = threading.Thread(target=self._run, daemon=True)
 
     def _run(self):
-        import subprocess
         while not self._stop:
-            try:
-                out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout
-                d = json.loads(out)
-                dev = int(os.environ.get("LOCAL_RANK", "0"))
-                c = d.get(f"card{dev}", d[sorted(d)[0]])
-                pw = [float(v) for k, v in c.items() if "Power (W)" in k and "Max" not in k]
-                ck = [float(str(v).strip("()").lower().replace("mhz", "")) for k, v in c.items() if k.lower().startswith("sclk clock speed")]
-                if pw and ck:
-                    self.samples.append((pw[0], ck[0]))
-            except Exception:
-                pass
+            for h, c in self.cards.items():
+                try:
+                    c["s"].append((int(open(os.path.join(h, "power1_input")).read()) * 1e-6, int(open(os.path.join(h, "freq1_input")).read()) * 1e-6))
+                except Exception:
+                    pass
             time.sleep(self.period)
 
     def start(self):
-        self._t.start()
+        if self.cards:
+            self._t.start()
 
     def stop(self):
         self._stop = True
-        if not self.samples:
+        best = None
+        for h, c in self.cards.items():
+            if c["s"]:
+                avg = sum(p for p, _ in c["s"]) / len(c["s"])
+                if best is None or avg > best[0]:
+                    best = (avg, h, c)
+        if best is None:
             return None
-        n = len(self.samples)
-        return {"power_w_avg": sum(p for p, _ in self.samples) / n, "power_w_max": max(p for p, _ in self.samples),
-                "sclk_mhz_avg": sum(c for _, c in self.samples) / n, "samples": n, "power_cap_w": 1400.0,
-                "source": "rocm-smi --showpower --showclocks, sampled every %.1f s over the timed region" % self.period}
+        _, h, c = best
+        n = len(c["s"])
+        cap = None
+        try:
+            cap = int(open(os.path.join(h, "power1_cap")).read()) * 1e-6
+        except Exception:
+            pass
+        return {"power_w_avg": sum(p for p, _ in c["s"]) / n, "power_w_max": max(p for p, _ in c["s"]),
+                "sclk_mhz_avg": sum(f for _, f in c["s"]) / n, "samples": n, "power_cap_w": cap, "pci": c["pci"],
+                "matched_by_pci_id": self.matched,
+                "source": "amdgpu hwmon (power1_input, freq1_input) in sysfs, sampled every %.2f s over the timed region" % self.period}
 
 
 def pmc_traffic(kind, micro_batch):
@@ -323,7 +346,7 @@ def main():
         break
     if not args.no_kernel_timing:
         ops.KTIMER = ops.KernelTimer()
-    board = BoardSampler() if rank == 0 else None
+    board = BoardSampler(local_rank) if rank == 0 else None
     if board is not None:
         board.start()
     t0 = time.perf_counter()

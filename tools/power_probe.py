@@ -1,61 +1,36 @@
-"""Board power / clock while ONE kernel kind runs back to back (rocm-smi sampled from a side thread): which kernels run at the
+"""Board power / clock while ONE kernel kind runs back to back (amdgpu hwmon files sampled from a side thread): which kernels run at the
 power cap, and at what clock.  python tools/power_probe.py   (GPU box)"""
-import os, subprocess, sys, threading, time
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from octcubem_amd import ops
 
-samples = []
-stop = False
+import bench          # BoardSampler: amdgpu hwmon files in sysfs (no child process after the GPU is initialised)
 
 
-def sampler():
-    while not stop:
-        try:
-            out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout
-            samples.append((time.time(), out))
-        except Exception as e:
-            samples.append((time.time(), "ERR " + repr(e)))
-        time.sleep(0.2)
-
-
-def summarize(name, t0, t1, per_call_ms):
-    import json
-    pw, sclk = [], []
-    for ts, out in samples:
-        if not (t0 + 0.5 <= ts <= t1):
-            continue
-        try:
-            d = json.loads(out)
-            c = d[sorted(d)[0]]
-            for k, v in c.items():
-                if "Power (W)" in k and "Max" not in k:
-                    pw.append(float(v))
-                if k.lower().startswith("sclk clock speed"):
-                    sclk.append(float(str(v).strip("()").lower().replace("mhz", "")))
-        except Exception:
-            pass
-    avg = lambda x: sum(x) / len(x) if x else float("nan")
-    print(f"{name:34s} {per_call_ms:9.3f} ms/call   power avg {avg(pw):7.1f} W (max {max(pw) if pw else float('nan'):7.1f}, {len(pw)} samples)   sclk avg {avg(sclk):7.1f} MHz", flush=True)
+def run_sampled(fn_loop):
+    b = bench.BoardSampler(0, period=0.1); b.start()
+    r = fn_loop()
+    st = b.stop()
+    return r, st
 
 
 def loop(name, fn, seconds=4.0):
     fn(); torch.cuda.synchronize()
-    t0 = time.time(); n = 0
-    while time.time() - t0 < seconds:
-        for _ in range(5):
-            fn()
-        torch.cuda.synchronize(); n += 5
-    t1 = time.time()
-    summarize(name, t0, t1, (t1 - t0) / n * 1e3)
+
+    def body():
+        t0 = time.time(); n = 0
+        while time.time() - t0 < seconds:
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize(); n += 5
+        return (time.time() - t0) / n * 1e3
+    ms, st = run_sampled(body)
+    st = st or {"power_w_avg": float("nan"), "power_w_max": float("nan"), "sclk_mhz_avg": float("nan"), "samples": 0}
+    print(f"{name:34s} {ms:9.3f} ms/call   power avg {st['power_w_avg']:7.1f} W (max {st['power_w_max']:7.1f}, {st['samples']} samples)   "
+          f"sclk avg {st['sclk_mhz_avg']:7.1f} MHz", flush=True)
 
 
-th = threading.Thread(target=sampler, daemon=True); th.start()
-time.sleep(1.0)
-try:
-    print(subprocess.run(["rocm-smi", "--showmaxpower"], capture_output=True, text=True, timeout=5).stdout.strip()[-300:])
-except Exception as e:
-    print("rocm-smi --showmaxpower:", e)
 g = torch.Generator(device="cuda").manual_seed(0)
 B = 128
 for zero in (False, True):
@@ -80,7 +55,5 @@ for zero in (False, True):
     loop(f"layernorm fwd{tag}", lambda: ops.layernorm_fwd(xf, gm, bt, 1e-6))
     del x, w, dy, gw, xf
 time.sleep(1.0)
-t0 = time.time(); time.sleep(2.0)
-summarize("idle", t0 - 0.5, time.time(), 0.0)
-stop = True
-print("first raw sample:", samples[0][1][:600] if samples else None)
+_, st = run_sampled(lambda: time.sleep(2.0))
+print("idle", st)
