@@ -33,7 +33,11 @@ int octmae_abi_version(void);
  *   "attn_bwd_hd64_form"   1 (default): one wave per SIMD, 4 x 64 keys per workgroup (csrc/attn_bwd1w64.hip)
  *                          0: two waves per SIMD, 8 x 32 keys (csrc/attn_bwd.hip); the two forms agree bit for bit
  *   "attn_bwd_tail_fused"  1 (default): the one-wave kernels also take the single key past the last full key block and the
- *                          workspace -> bf16 conversion of their (batch, head); 0: the separate launch (same results) */
+ *                          workspace -> bf16 conversion of their (batch, head); 0: the separate launch (same results)
+ *   "gemm_mfma16"          0 (default): the 256-tile forward / dgrad GEMMs on v_mfma_f32_32x32x16_bf16 (gemm256p_kernel);
+ *                          1: on v_mfma_f32_16x16x32_bf16 (gemm256q_kernel: same tile, staging and epilogues; 3 % faster alone,
+ *                          no faster in the training step -- DESIGN.md section 4).  Bit 11 (0x800) of octmae_gemm_bf16's
+ *                          `epilogue` argument forces the 32x32x16 form for one call (bits 8-10: tile / main-loop variants) */
 int octmae_set_option(const char* key, int value);
 
 /* ---- GEMM with fused epilogues ------------------------------------------------------------------
