@@ -216,3 +216,30 @@ def test_native_comm_bootstrap_over_a_store(monkeypatch):
         t.join(timeout=30)
     assert made == {r: (the_id, 3, r) for r in range(3)}
     assert len(the_id) == ocomm.ID_BYTES == 128
+
+
+def test_bench_board_sampler_without_hwmon_reports_nothing(tmp_path, monkeypatch):
+    """bench.BoardSampler reads the amdgpu hwmon files by plain file reads (no child process after the GPU is initialised); on a
+    host without them -- this container -- it must start, stop and report None instead of failing the benchmark."""
+    import glob
+    import bench
+    monkeypatch.setattr(glob, "glob", lambda pat, **kw: [])
+    b = bench.BoardSampler(0, period=0.01)
+    assert b.cards == {}
+    b.start()
+    assert b.stop() is None
+
+
+def test_bench_board_sampler_reads_power_and_clock(tmp_path, monkeypatch):
+    import glob
+    import time
+    import bench
+    h = tmp_path / "card0" / "device" / "hwmon" / "hwmon3"
+    h.mkdir(parents=True)
+    (h / "power1_input").write_text("1350000000\n"); (h / "freq1_input").write_text("1950000000\n"); (h / "power1_cap").write_text("1400000000\n")
+    monkeypatch.setattr(glob, "glob", lambda pat, **kw: [str(h)])
+    b = bench.BoardSampler(0, period=0.01)
+    b.start(); time.sleep(0.1)
+    st = b.stop()
+    assert st is not None and st["samples"] >= 2
+    assert abs(st["power_w_avg"] - 1350.0) < 1e-6 and abs(st["sclk_mhz_avg"] - 1950.0) < 1e-6 and st["power_cap_w"] == 1400.0
