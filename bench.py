@@ -72,6 +72,7 @@ def cpu_baseline(timed_iters=3):
 _PMC_KERNEL = {"gemm_wgrad_epi5": ["gemm256p_kernel<true, true, 5, true>", "gemm256_kernel<true, true, 5, true>"],
                "gemm_dgrad_epi0": ["gemm256p_kernel<true, false, 0, false>", "gemm256_kernel<true, false, 0, false>"],
                "gemm_dgrad_epi4": ["gemm256p_kernel<true, false, 4, false>", "gemm256_kernel<true, false, 4, false>"],
+               "gemm_dgrad_epi6": ["gemm256p_kernel<true, false, 6, false>"],      # proj dgrad + the attention backward's delta (round 4)
                "gemm_fwd_epi0": ["gemm256p_kernel<false, false, 0, false>", "gemm256_kernel<false, false, 0, false>"], "gemm_fwd_epi2": ["gemm256p_kernel<false, false, 2, false>", "gemm256_kernel<false, false, 2, false>"],
                "gemm_fwd_epi3": ["gemm256p_kernel<false, false, 3, false>", "gemm256_kernel<false, false, 3, false>"],
                "attn_fwd_hd32": ["attn_fwd_kernel<32, true>"], "attn_fwd_hd64": ["attn_fwd_kernel<64, true>"],
@@ -82,8 +83,12 @@ _PMC_KERNEL = {"gemm_wgrad_epi5": ["gemm256p_kernel<true, true, 5, true>", "gemm
                "ln_fwd_d1024": ["ln_fwd_kernel<4>"], "ln_fwd_d512": ["ln_fwd_kernel<2>"]}
 # A timed kind that is one C-ABI entry point but several launches: the HIP events bracket the whole entry, so `avg_launch_us`
 # is the SUM of these kernels' average durations in a rocprofv3 summary, and `traffic` the sum of their bytes.
-_LAUNCH_GROUP = {"attn_bwd_fused_hd32": ["attn_rowconst_pad_kernel<32>", "attn_bwd_fused1w_kernel"],
-                 "attn_bwd_fused_hd64": ["attn_rowconst_pad_kernel<64>", "attn_bwd_fused1w64_kernel"]}
+# (since round 4 the per-query constants come from the delta the proj dgrad GEMM wrote: attn_rowconst_from_delta_kernel only
+# transposes and pads; PMC files taken before that list attn_rowconst_pad_kernel<HD> instead -- the second form below)
+_LAUNCH_GROUP = {"attn_bwd_fused_hd32": ["attn_rowconst_from_delta_kernel", "attn_bwd_fused1w_kernel"],
+                 "attn_bwd_fused_hd64": ["attn_rowconst_from_delta_kernel", "attn_bwd_fused1w64_kernel"]}
+_LAUNCH_GROUP_OLD = {"attn_bwd_fused_hd32": ["attn_rowconst_pad_kernel<32>", "attn_bwd_fused1w_kernel"],
+                     "attn_bwd_fused_hd64": ["attn_rowconst_pad_kernel<64>", "attn_bwd_fused1w64_kernel"]}
 # (N = 5121 and 1281 leave ONE key past the last full key block: the one-wave main kernels take it, and the workspace -> bf16
 # conversion, at their end -- attn_bwd_tail1.hpp; until mid round 3 that was a third launch, attn_bwd_tail1_kernel)
 
@@ -164,9 +169,9 @@ def pmc_traffic(kind, micro_batch):
             meta = t.get("_meta", {})
             if int(meta.get("micro_batch", 32)) != micro_batch:
                 continue
-            group = _LAUNCH_GROUP.get(kind)
-            if group and all(name in t for name in group):
-                return (sum(t[name]["hbm_bytes_per_launch_corrected"] for name in group), os.path.basename(path), meta.get("head"))
+            for group in (_LAUNCH_GROUP.get(kind), _LAUNCH_GROUP_OLD.get(kind)):
+                if group and all(name in t for name in group):
+                    return (sum(t[name]["hbm_bytes_per_launch_corrected"] for name in group), os.path.basename(path), meta.get("head"))
             for name in _PMC_KERNEL.get(kind, []):
                 if name in t:
                     return t[name]["hbm_bytes_per_launch_corrected"], os.path.basename(path), meta.get("head")

@@ -22,8 +22,9 @@ extern "C" {
 
 /* The ONE place the ABI number lives: octmae_abi_version() returns it (csrc/probe.hip), octcubem_amd/_lib.py parses it
  * from this header and refuses a library that reports another number, __graft_entry__.build() and the tests compare the two.
- * 4: octmae_attn_bwd_dq_rowconst.  5: octmae_comm_* (RCCL), octmae_attn_bwd_fused + workspace query.  7: octmae_set_option, octmae_scatter_add_rows, octmae_dec_assemble_bwd. */
-#define OCTMAE_ABI_VERSION 7
+ * 4: octmae_attn_bwd_dq_rowconst.  5: octmae_comm_* (RCCL), octmae_attn_bwd_fused + workspace query.  7: octmae_set_option, octmae_scatter_add_rows, octmae_dec_assemble_bwd.
+ * 8: octmae_linear_dgrad_delta, octmae_attn_bwd_fused_delta. */
+#define OCTMAE_ABI_VERSION 8
 int octmae_abi_version(void);
 
 /* Kernel-selection switches for same-process A/B measurements and for tests that cover both forms of a kernel (no reference
@@ -71,6 +72,17 @@ int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2, const floa
 int octmae_dgelu_colsum_ws_rows(int M);
 int octmae_linear_dgrad_dgelu(const void* W, const void* dY, void* dX, const void* pre, float* ws, float* bias_grad,
                               int M, int N, int K, int ldw, int ldy, int ldx, int ldpre, int small_tile, void* stream);
+
+/* The proj dgrad of an attention block together with the attention backward's per-query constant delta (flash-attn's `dsoftmax_sum`,
+ * the backward of video_vit.py:130-134 under autograd):
+ *   dX bf16 [M][K] = dY[M][N] @ W[N][K],   delta f32 [M][H] = -sum over each head's hd columns of dX * O     (O bf16 [M][K], K = H hd)
+ * dX is the gradient of the attention output O; the fused attention backward needs rowsum(dO * O) per query and head, which is a
+ * full extra pass over O and dO when computed on its own (0.13 / 0.25 ms per call at the ViT-L shapes) and 8 multiply-adds per
+ * lane in this GEMM's epilogue, whose tiles hold whole heads.  delta is computed from the bf16-ROUNDED dX (what the attention
+ * backward reads).  Returns -2 when the problem does not take the 256-tile kernel (M or K < 256, N % 64 != 0, K % 8 != 0): the
+ * caller then uses octmae_gemm_bf16 and octmae_attn_bwd_fused.  variant: kernel-selection bits (bit 8 forces "not applicable"). */
+int octmae_linear_dgrad_delta(const void* W, const void* dY, void* dX, const void* O, float* delta, int M, int N, int K, int ldw,
+                              int ldy, int ldx, int ldo, int H, int hd, int variant, void* stream);
 
 /* Stochastic depth (timm DropPath around both Block branches, video_vit.py:181-184 with drop_path > 0; fine-tune drivers use
  * 0.1-0.2): out f32 [M][N] = res + rowscale[m / rows_per_scale] * (X[M][K] @ W[N][K]^T + bias) -- the per-sample keep mask
@@ -125,6 +137,10 @@ int octmae_attn_bwd_dkv(const void* qkv, const void* dout, const float* rowc, vo
 int octmae_attn_bwd_fused_ws_kib(int B, int N, int H, int HD);
 int octmae_attn_bwd_fused(const void* qkv, const void* o, const void* dout, const float* lse, void* ws, void* dqkv, int B, int N,
                           int H, int HD, float scale, void* stream);
+/* octmae_attn_bwd_fused with delta (fp32 [B * N][H], from octmae_linear_dgrad_delta) supplied instead of O: the per-query constants are
+ * transposed and padded from it, no pass over O and dO.  Same workspace, same outputs. */
+int octmae_attn_bwd_fused_delta(const void* qkv, const void* dout, const float* lse, const float* delta, void* ws, void* dqkv, int B,
+                                int N, int H, int HD, float scale, void* stream);
 
 /* ---- random masking indices ---------------------------------------------------------------------
  * MaskedAutoencoderViT.random_masking index part, models_mae_joint_res_flash_attn.py:349-369:

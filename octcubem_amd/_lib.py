@@ -25,6 +25,7 @@ SIGNATURES = {
     "octmae_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "octmae_attn_bwd_fused_ws_kib": [_i, _i, _i, _i],
     "octmae_attn_bwd_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "octmae_attn_bwd_fused_delta": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "octmae_attn_bwd_rowconst": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "octmae_attn_bwd_dq_rowconst": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "octmae_attn_bwd_dq": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
@@ -36,6 +37,7 @@ SIGNATURES = {
     "octmae_colsum_accum": [_vp, _i, _vp, _i, _i, _i, _vp],
     "octmae_dgelu_colsum_ws_rows": [_i],
     "octmae_linear_dgrad_dgelu": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "octmae_linear_dgrad_delta": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "octmae_patch_gather": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "octmae_enc_assemble": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "octmae_dec_assemble": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -205,6 +205,39 @@ __global__ __launch_bounds__(256) void attn_rowconst_pad_kernel(const bf16_t* __
   }
 }
 
+// The same padded planes from a delta that already exists: delta[B * N][H] (fp32, -rowsum(dO * O) per token row and head), written by
+// the epilogue of the proj dgrad GEMM that produced dO (octmae_linear_dgrad_delta, csrc/gemm.hip) -- no second pass over O and dO.
+// One workgroup per 64 (padded) query rows of a sample: the [64][H] block of delta is contiguous; it crosses LDS and leaves as 64
+// contiguous floats per head, beside -lse * log2e.
+__global__ __launch_bounds__(256) void attn_rowconst_from_delta_kernel(const float* __restrict__ delta, const float* __restrict__ lse,
+                                                                       float* __restrict__ rowc, int B, int N, int NPAD, int H) {
+  __shared__ float sh[64][64 + 1];              // [row][head]   (H <= 64)
+  const size_t plane = (size_t)B * H * NPAD;
+  const int tid = threadIdx.x;
+  const int tiles_per_b = NPAD / 64;
+  for (int blk = blockIdx.x; blk < B * tiles_per_b; blk += gridDim.x) {
+    const int b = blk / tiles_per_b, q0 = (blk % tiles_per_b) * 64;
+    for (int i = tid; i < 64 * H; i += 256) {
+      const int rl = i / H, hh = i - rl * H;
+      sh[rl][hh] = (q0 + rl < N) ? delta[((size_t)b * N + q0 + rl) * H + hh] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < 16 * H; i += 256) {   // head i / 16, rows 4 (i % 16) .. + 3
+      const int hh = i >> 4, r4 = (i & 15) * 4;
+      const size_t i0 = ((size_t)b * H + hh) * NPAD + q0 + r4;
+      f32x4 vl, vd;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int q = q0 + r4 + e;
+        vl[e] = (q < N) ? -lse[((size_t)b * H + hh) * N + q] * LOG2E : -1.0e30f;
+        vd[e] = sh[r4 + e][hh];
+      }
+      *reinterpret_cast<f32x4*>(rowc + i0) = vl;
+      *reinterpret_cast<f32x4*>(rowc + plane + i0) = vd;
+    }
+    __syncthreads();
+  }
+}
 
 // =====================================================================================================
 // main kernel: the full key blocks
@@ -790,7 +823,7 @@ std::atomic<int> g_attn_bwd_hd64_form{1};
 
 template <int HD>
 static int run_fused(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, const float* lse, float* ws, bf16_t* dqkv, int B, int N,
-                     int H, float scale, hipStream_t st) {
+                     int H, float scale, hipStream_t st, const float* delta = nullptr) {
   using C = BwdCfg<HD>;
   // one all-padding tile of row constants behind the last query tile: (-1e30, 0), i.e. P = 0 -- the one-wave-per-SIMD kernel
   // drains its software pipeline on it
@@ -800,7 +833,11 @@ static int run_fused(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, con
   {
     int blocks = B * (NPAD / 64);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(attn_rowconst_pad_kernel<HD>, dim3(blocks), dim3(256), 0, st, o, dout, lse, rowc, B, N, NPAD, H);
+    if (delta != nullptr) {   // delta came with dO (octmae_linear_dgrad_delta): transpose + pad only
+      hipLaunchKernelGGL(attn_rowconst_from_delta_kernel, dim3(blocks), dim3(256), 0, st, delta, lse, rowc, B, N, NPAD, H);
+    } else {
+      hipLaunchKernelGGL(attn_rowconst_pad_kernel<HD>, dim3(blocks), dim3(256), 0, st, o, dout, lse, rowc, B, N, NPAD, H);
+    }
     OCTMAE_LAUNCH_CHECK();
   }
   const int nkb = N / C::KB;
@@ -874,4 +911,19 @@ extern "C" int octmae_attn_bwd_fused(const void* qkv, const void* o, const void*
   bf16_t* out = reinterpret_cast<bf16_t*>(dqkv);
   float* w = reinterpret_cast<float*>(ws);
   return HD == 64 ? run_fused<64>(q, oo, dd, lse, w, out, B, N, H, scale, st) : run_fused<32>(q, oo, dd, lse, w, out, B, N, H, scale, st);
+}
+
+// The same with delta = -rowsum(dO * O) per token row and head (fp32 [B * N][H]) supplied by the caller -- written by the epilogue of
+// the GEMM that produced dO (octmae_linear_dgrad_delta) -- instead of a pass over O and dO.
+extern "C" int octmae_attn_bwd_fused_delta(const void* qkv, const void* dout, const float* lse, const float* delta, void* ws, void* dqkv, int B,
+                                     int N, int H, int HD, float scale, void* stream) {
+  OCTMAE_CHECK_ARG(qkv && delta && dout && lse && ws && dqkv && H <= 64 && B > 0 && N > 0 && H > 0 && (HD == 64 || HD == 32));
+  OCTMAE_CHECK_ARG(((size_t)N * 3 * H * HD * 2) < 0xFFFFFFFFull);      // one sample's qkv rows within a 32-bit buffer range
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bf16_t* q = reinterpret_cast<const bf16_t*>(qkv);
+  const bf16_t* oo = nullptr;
+  const bf16_t* dd = reinterpret_cast<const bf16_t*>(dout);
+  bf16_t* out = reinterpret_cast<bf16_t*>(dqkv);
+  float* w = reinterpret_cast<float*>(ws);
+  return HD == 64 ? run_fused<64>(q, oo, dd, lse, w, out, B, N, H, scale, st, delta) : run_fused<32>(q, oo, dd, lse, w, out, B, N, H, scale, st, delta);
 }

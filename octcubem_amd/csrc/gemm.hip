@@ -34,6 +34,9 @@ enum Epi : int {
   EPI_RESID = 3,     // C f32  = aux_f32 + X + bias
   EPI_DGELU = 4,     // C bf16 = X * gelu'(aux_bf16)
   EPI_ACCUM = 5,     // C f32 += X   (OUT_AB; atomics when split-K > 1)
+  EPI_DELTA = 6,     // C bf16 = X, C2 f32 [NB][ldc2]: C2[b][a / hd] = -sum_{j < hd} bf16(X[b][a0 + j]) * aux_bf16[b][a0 + j]
+                     //   (the attention backward's per-query delta = rowsum(dO * O), from the proj dgrad that produces dO;
+                     //   256-tile LDS-transposing epilogue only)
 };
 
 struct GemmParams {
@@ -50,6 +53,7 @@ struct GemmParams {
   const float* rowscale;   // EPI_RESID only: C = aux + rowscale[b / rows_per_scale] * (X + bias)   (stochastic depth); NULL = 1
   int rows_per_scale;
   int cgroup;              // 256-tile kernels: column tiles (a) per group of the tile order, see tile_coord()
+  int hd;                  // EPI_DELTA: head dimension (32 or 64: a head is 4 or 8 lanes of the epilogue's read side)
   int ldc2;                // EPI_DGELU column sums: 0 = C2 is an fp32 [NA] vector (atomics); > 0 = C2 is fp32 [NB / 64][ldc2],
                            // one row of partial sums per 64-row slab, plain stores (folded by a second launch)
 };
@@ -369,14 +373,14 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, AccT& acc
   const int r = lane & 31, h = lane >> 5;
   [[maybe_unused]] const int c16 = lane & 15, q4 = lane >> 4;
   const int rrow = lane >> 4, rc = lane & 15;   // read side: 16 lanes per 256-B row, 4 rows per instruction
-  if (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU) {
+  if (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU || EPI == EPI_DELTA) {
     // bf16 image [64 b][128 a].  EPI_DGELU multiplies by gelu'(pre) on the read side: the product of the bf16-rounded
     // dgrad with gelu' is rounded once more -- the numerics of an autocast GELU backward, which also reads a bf16 dgrad.
     const int a = a_base + rc * 8;
     const bool a_ok = a < p.NA;
     const unsigned o_out = a_ok ? (unsigned)(rrow * p.ldc + a) * 2u : EPI_OOB;
     u32x4 prev[16];
-    if (EPI == EPI_DGELU) {   // all 16 pre-activation row segments requested before the transpose
+    if (EPI == EPI_DGELU || EPI == EPI_DELTA) {   // all 16 pre-activation (attention-output) row segments requested before the transpose
       const __amdgpu_buffer_rsrc_t rx = epi_rsrc(p.aux, b_base, p.NB, p.ldaux, 2);
       const unsigned o_aux = a_ok ? (unsigned)(rrow * p.ldaux + a) * 2u : EPI_OOB;
 #pragma unroll
@@ -391,7 +395,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, AccT& acc
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int g = 0; g < 4; ++g) bias_q[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (EPI != EPI_DGELU && p.bias != nullptr) {
+    if (EPI != EPI_DGELU && EPI != EPI_DELTA && p.bias != nullptr) {
       if constexpr (!Q) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -450,6 +454,20 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, AccT& acc
 #pragma unroll
             for (int e = 0; e < 4; ++e) { cs[2 * e] += bflo(v[e]); cs[2 * e + 1] += bfhi(v[e]); }
           }
+        }
+        if (EPI == EPI_DELTA) {
+          // delta of this row and head from the bf16-ROUNDED dO the attention backward will read, summed in the order of
+          // attn_rowconst_pad_kernel (8 elements per lane, then a butterfly over the hd / 8 lanes of the head)
+          const u32x4 oo = prev[it];   // zeros outside the matrix
+          float sum = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sum += bflo(oo[e]) * bflo(v[e]) + bfhi(oo[e]) * bfhi(v[e]);
+          sum += __shfl_xor(sum, 1, 64);
+          sum += __shfl_xor(sum, 2, 64);
+          if (p.hd == 64) sum += __shfl_xor(sum, 4, 64);
+          const int lph = p.hd >> 3;
+          if ((rc & (lph - 1)) == 0 && a_ok && b_base + row < p.NB)
+            reinterpret_cast<float*>(p.C2)[(size_t)(b_base + row) * p.ldc2 + (a >> (p.hd == 64 ? 6 : 5))] = -sum;
         }
         __builtin_amdgcn_raw_buffer_store_b128(v, ro, o_out + it * 4 * p.ldc * 2, 0, EPI_STORE_AUX);
       }
@@ -1197,7 +1215,7 @@ static int gemm_impl(const void* A, const void* B, void* C, void* C2, const floa
   // stand-alone column-sum kernel.
   float* dgelu_colsum = (epilogue == EPI_DGELU) ? reinterpret_cast<float*>(C2) : nullptr;
   if (epilogue == EPI_DGELU && !(big && (NA & 7) == 0)) p.C2 = nullptr;
-  p.ldc2 = 0;
+  p.ldc2 = 0; p.hd = 0;
   const int ws_rows = 4 * p.tiles_b;             // 64-row slabs of the 256-tile grid
   if (epilogue == EPI_DGELU && p.C2 != nullptr && colsum_ws != nullptr) { p.C2 = colsum_ws; p.ldc2 = NA; }
 #define OCTMAE_GEMM_CASE(AKS, BKS, E, AB)                                  \
@@ -1242,6 +1260,36 @@ extern "C" int octmae_linear_resid_rowscale(const void* W, const void* X, float*
   OCTMAE_CHECK_ARG(rowscale != nullptr && rows_per_scale > 0);
   return gemm_impl(W, X, out, nullptr, bias, res, N, M, K, ldw, ldx, ldout, ldres, 0, 0, EPI_RESID | (small_tile & 0xF00), 1,
                    stream, rowscale, rows_per_scale);
+}
+
+// dX[M][K] bf16 = dY[M][N] @ W[N][K]  and  delta[M][H] f32 = -sum over each head's hd columns of dX * O  (O bf16 [M][K], K = H * hd):
+// the proj dgrad of an attention block, whose output dO the attention backward multiplies with O row by row anyway.
+// Returns -2 when the problem does not take the 256-tile kernel (the caller then uses octmae_gemm_bf16 + octmae_attn_bwd_fused).
+extern "C" int octmae_linear_dgrad_delta(const void* W, const void* dY, void* dX, const void* O, float* delta, int M, int N, int K,
+                                         int ldw, int ldy, int ldx, int ldo, int H, int hd, int variant, void* stream) {
+  OCTMAE_CHECK_ARG(W && dY && dX && O && delta && M > 0 && N > 0 && K > 0);
+  OCTMAE_CHECK_ARG((hd == 32 || hd == 64) && H > 0 && H * hd == K && (ldw % 8) == 0 && (ldy % 8) == 0 && (ldx % 4) == 0 && (ldo % 4) == 0);
+  OCTMAE_CHECK_ARG(K % 8 == 0 && N % 8 == 0);
+  const size_t a_bytes = (size_t)N * ldw * 2, b_bytes = (size_t)M * ldy * 2;
+  const bool big = K >= T2 && M >= T2 && a_bytes < 0xFFF00000ull && b_bytes < 0xFFF00000ull && ((variant >> 8) & 1) == 0 &&
+                   (N % TK) == 0 && (K & 7) == 0;
+  if (!big) return -2;
+  GemmParams p;
+  p.A = reinterpret_cast<const bf16_t*>(W); p.B = reinterpret_cast<const bf16_t*>(dY);
+  p.C = dX; p.C2 = delta; p.bias = nullptr; p.aux = O; p.rowscale = nullptr; p.rows_per_scale = 1;
+  p.NA = K; p.NB = M; p.K = N; p.lda = ldw; p.ldb = ldy; p.ldc = ldx; p.ldaux = ldo;
+  p.ktiles = (N + TK - 1) / TK; p.ktiles_per_split = p.ktiles;
+  p.tiles_a = (K + T2 - 1) / T2; p.tiles_b = (M + T2 - 1) / T2;
+  p.cgroup = p.tiles_a;
+  if (p.tiles_a >= 16 && p.tiles_a % 4 == 0 && 4 * (size_t)T2 * N * 2 <= (2u << 20)) p.cgroup = 4;
+  p.hd = hd; p.ldc2 = H;
+  auto kern = gemm256p_kernel<true, false, EPI_DELTA, false>;
+  static DynLdsOnce once;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (int rc = once.ensure(reinterpret_cast<const void*>(kern), 4 * TILE2_BYTES)) return rc;
+  hipLaunchKernelGGL(kern, dim3(p.tiles_a * p.tiles_b, 1, 1), dim3(512), 4 * TILE2_BYTES, st, p);
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int octmae_dgelu_colsum_ws_rows(int M) { return M > 0 ? 4 * ((M + T2 - 1) / T2) : 0; }

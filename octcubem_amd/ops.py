@@ -259,6 +259,26 @@ def linear_dgrad(dy: torch.Tensor, w: torch.Tensor, pre: Optional[torch.Tensor] 
     return dx
 
 
+DGRAD_DELTA = True     # the proj dgrad also produces the attention backward's delta (octmae_linear_dgrad_delta); A/B: bench.py --set ops.DGRAD_DELTA=0
+
+
+def linear_dgrad_delta(dy: torch.Tensor, w: torch.Tensor, o: torch.Tensor, H: int, HD: int):
+    """dx[M,K] = dy[M,N] @ w[N,K] (bf16) and delta[M,H] (fp32) = -sum over each head's HD columns of dx * o -- the attention
+    backward's per-query constant, from the epilogue of the GEMM that produces dO (no separate pass over O and dO).
+    Returns (dx, None) when the shape does not take the fused kernel (the caller then lets octmae_attn_bwd_fused compute it)."""
+    M, N = dy.shape
+    K = w.shape[1]
+    if not (DGRAD_DELTA and not FORCE_SMALL_TILE and M >= 256 and K >= 256 and N % 64 == 0 and K % 8 == 0 and H * HD == K and H <= 64
+            and HD in (32, 64)):
+        return linear_dgrad(dy, w), None
+    dx = torch.empty((M, K), dtype=BF16, device=dy.device)
+    delta = torch.empty((M, H), dtype=F32, device=dy.device)
+    args = (w.data_ptr(), dy.data_ptr(), dx.data_ptr(), o.data_ptr(), delta.data_ptr(), M, N, K, w.stride(0), dy.stride(0), K, o.stride(0),
+            H, HD, _variant_bits(), _stream())
+    _launch("gemm_dgrad_epi6", 2.0 * K * M * N, 2.0 * (K * N + M * N) + 2.0 * K * M + 2.0 * K * M, lambda: call("octmae_linear_dgrad_delta", *args))
+    return dx, delta
+
+
 def _splitk_for(n_out_tiles: int, ktiles: int, target_blocks: int) -> int:
     # as many k-slices as keep tiles x slices within ONE round of workgroups over the chip (a second, partly filled
     # round costs more than the slightly lower fill), and >= 8 k-tiles (512 token rows) per slice
@@ -336,9 +356,10 @@ def set_option(key: str, value: int) -> int:
     return prev
 
 
-def attn_bwd(qkv, o, dout, lse, B, N, H, HD, scale, fused: Optional[bool] = None):
+def attn_bwd(qkv, o, dout, lse, B, N, H, HD, scale, fused: Optional[bool] = None, delta: Optional[torch.Tensor] = None):
     """Gradient of attn_fwd w.r.t. the packed qkv.  Algorithmic work ("x3" in total): 4 matrix products =
-    8 B H N^2 HD flop (dP, dV, dK, dQ); the recomputation of S is not counted."""
+    8 B H N^2 HD flop (dP, dV, dK, dQ); the recomputation of S is not counted.  ``delta`` (fp32 [B * N, H], from
+    linear_dgrad_delta): the fused form then skips its pass over O and dO."""
     dqkv = torch.empty_like(qkv)
     st = _stream()
     unit = 2.0 * B * H * N * N * HD
@@ -348,6 +369,12 @@ def attn_bwd(qkv, o, dout, lse, B, N, H, HD, scale, fused: Optional[bool] = None
             raise RuntimeError("octmae_attn_bwd_fused_ws_kib: unsupported shape")
         ws = torch.empty((kib * 256,), dtype=F32, device=qkv.device)     # dQ fp32 + padded row constants (contents irrelevant)
         # executes 5 products (S once); plus an fp32 read-modify-write of dQ per key block
+        if delta is not None:
+            _chk(delta, F32, "delta")
+            _launch(f"attn_bwd_fused_hd{HD}", 4 * unit, 2.0 * 6 * B * N * H * HD,
+                    lambda: call("octmae_attn_bwd_fused_delta", qkv.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                 ws.data_ptr(), dqkv.data_ptr(), B, N, H, HD, float(scale), st), exec_flops=5 * unit)
+            return dqkv
         _launch(f"attn_bwd_fused_hd{HD}", 4 * unit, 2.0 * 6 * B * N * H * HD,
                 lambda: call("octmae_attn_bwd_fused", qkv.data_ptr(), o.data_ptr(), dout.data_ptr(), lse.data_ptr(), ws.data_ptr(),
                              dqkv.data_ptr(), B, N, H, HD, float(scale), st), exec_flops=5 * unit)
@@ -502,8 +529,9 @@ class AttentionFn(torch.autograd.Function):
         if gbproj is not None:
             colsum_accum(d2 if d2.dtype in (F32, BF16) else dob, gbproj)
         linear_wgrad_accum(dob, o, gwproj)
-        do = linear_dgrad(dob, wproj_lp)
-        dqkv = attn_bwd(qkv, o, do, lse, Bn, N, H, HD, scale)
+        fused_bwd = ATTN_BWD_FUSED[HD]
+        do, delta = linear_dgrad_delta(dob, wproj_lp, o, H, HD) if fused_bwd else (linear_dgrad(dob, wproj_lp), None)
+        dqkv = attn_bwd(qkv, o, do, lse, Bn, N, H, HD, scale, delta=delta)
         linear_wgrad_accum(dqkv, y2, gwqkv, gbqkv)
         notify_grad_ready(ctx.params)
         dy = linear_dgrad(dqkv, wqkv_lp).view(ctx.shp)
@@ -655,8 +683,9 @@ class BlockFn(torch.autograd.Function):
                 colsum_accum(dx2b, gbproj)
         # ---- attention
         linear_wgrad_accum(dx2b, o, gwproj)
-        do = linear_dgrad(dx2b, wproj)
-        dqkv = attn_bwd(qkv, o, do, lse, Bn, N, H, HD, scale)
+        fused_bwd = ATTN_BWD_FUSED[HD]
+        do, delta = linear_dgrad_delta(dx2b, wproj, o, H, HD) if fused_bwd else (linear_dgrad(dx2b, wproj), None)
+        dqkv = attn_bwd(qkv, o, do, lse, Bn, N, H, HD, scale, delta=delta)
         # the qkv bias gradient rides in the weight-gradient GEMM (column sums of its dY operand); fusing it into the attention
         # backward kernels had been measured and dropped (+10..25 % on their main loops for a 2 % pass)
         linear_wgrad_accum(dqkv, y1, gwqkv, gbqkv)

@@ -429,6 +429,39 @@ def test_attention_backward_fused_row_constants(HD, N):
     assert torch.equal(ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, scale, fused=False), d1)     # the host wrapper's two-kernel form
 
 
+@pytest.mark.parametrize("B,N,H,HD", [(2, 1281, 16, 64), (1, 5121, 16, 32), (3, 300, 8, 32), (2, 257, 4, 64), (1, 1000, 12, 64)])
+def test_proj_dgrad_produces_the_attention_delta(B, N, H, HD, tile_variant):
+    """octmae_linear_dgrad_delta: the proj dgrad GEMM whose epilogue also writes delta = -rowsum_head(dO * O) (fp32 [B N][H]) from
+    the bf16-rounded dO it stores, and octmae_attn_bwd_fused_delta, which takes that delta instead of a pass over O and dO
+    (backward of video_vit.py:130-134; flash-attn's dsoftmax_sum).  Against fp64 on the same rounded operands; the gradients of
+    the fused attention backward must be those of the stand-alone form (the constants differ only in fp32 summation order); ragged
+    row counts; shapes the fused GEMM does not take fall back (delta None) and everything still agrees."""
+    C = H * HD
+    M = B * N
+    g = torch.Generator().manual_seed(B * N + HD)
+    qkv = bf(torch.randn(M, 3 * C, generator=g)).to(DEV)
+    dy = bf(torch.randn(M, C, generator=g)).to(DEV)                     # gradient entering the proj dgrad
+    w = bf(torch.randn(C, C, generator=g) * C ** -0.5).to(DEV)
+    scale = HD ** -0.5
+    o, lse = ops.attn_fwd(qkv, B, N, H, HD, scale)
+    do_ref = ops.linear_dgrad(dy, w)
+    do, delta = ops.linear_dgrad_delta(dy, w, o, H, HD)
+    assert torch.equal(do, do_ref)                                       # the GEMM itself is unchanged
+    expect_fused = tile_variant != "tile128" and M >= 256 and C >= 256
+    assert (delta is not None) == expect_fused
+    if delta is not None:
+        ref = -(do.double() * o.double()).view(M, H, HD).sum(-1)
+        assert float((delta.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-6
+    d_sep = ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, scale, fused=True)
+    d_new = ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, scale, fused=True, delta=delta)
+    assert rel(d_new, d_sep) <= 2e-5
+    if delta is not None:   # fed the stand-alone kernel's own sums, the delta entry point reproduces it bit for bit
+        exact = -(do.float() * o.float()).view(M, H, HD).sum(-1)
+        d_a = ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, scale, fused=True, delta=exact.contiguous())
+        d_b = ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, scale, fused=True, delta=exact.contiguous())
+        assert torch.equal(d_a, d_b) and rel(d_a, d_sep) <= 2e-5
+
+
 @pytest.mark.parametrize("HD", [64, 32])
 def test_attention_online_softmax_rescale_branch(HD):
     """Force the running max to jump at a late key tile (one query/key pair with a huge score)."""
