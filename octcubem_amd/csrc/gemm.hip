@@ -367,6 +367,12 @@ constexpr unsigned EPI_OOB = 0x7ffffff0u;
 // Q = false: acc is f32x16[4][2], the 32x32 C layout above.  Q = true: acc is f32x4[8][4], 16 x 16 tiles (a-tile ti, b-tile tj)
 // of v_mfma_f32_16x16x32_bf16: register e of lane (c16 = lane & 15, q4 = lane >> 4) is X[a_base + 16 ti + 4 q4 + e][b_base + 16 tj + c16].
 // Either way a lane holds quads of 4 consecutive a of one output row b, so only the WRITE side of the transpose differs.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {      // x + (x of the lane CTRL selects), all lanes active
+  const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true);
+  return x + __builtin_bit_cast(float, y);
+}
+
 template <int EPI, bool Q = false, class AccT>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, AccT& acc, int a_base, int b_base, int lane,
                                                   char* wl) {
@@ -462,9 +468,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, AccT& acc
           float sum = 0.f;
 #pragma unroll
           for (int e = 0; e < 4; ++e) sum += bflo(oo[e]) * bflo(v[e]) + bfhi(oo[e]) * bfhi(v[e]);
-          sum += __shfl_xor(sum, 1, 64);
-          sum += __shfl_xor(sum, 2, 64);
-          if (p.hd == 64) sum += __shfl_xor(sum, 4, 64);
+          // butterfly over the head's lanes on DPP (quad_perm [1,0,3,2], [2,3,0,1], then row_half_mirror: every lane of a quad
+          // holds the quad's sum by then, so mirroring the 8-lane half adds the other quad's) -- the same additions as
+          // __shfl_xor 1, 2, 4, which hipcc lowers to ds_bpermute (48 dependent LDS round trips per wave here)
+          sum = dpp_add<0xB1>(sum);
+          sum = dpp_add<0x4E>(sum);
+          if (p.hd == 64) sum = dpp_add<0x141>(sum);
           const int lph = p.hd >> 3;
           if ((rc & (lph - 1)) == 0 && a_ok && b_base + row < p.NB)
             reinterpret_cast<float*>(p.C2)[(size_t)(b_base + row) * p.ldc2 + (a >> (p.hd == 64 ? 6 : 5))] = -sum;
