@@ -35,15 +35,41 @@ __device__ __forceinline__ float bflo(uint32_t w) { return __builtin_bit_cast(fl
 __device__ __forceinline__ float bfhi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 
 // ---- wave reductions (64 lanes) -------------------------------------------------------------
+// Wave-wide reductions on DPP (every lane of the wave must be active: all call sites sit in wave-uniform control flow).  hipcc lowers
+// __shfl_xor to ds_bpermute -- an LDS round trip per step, six dependent ones per reduction (two reductions per LayerNorm row) -- where
+// the 16-lane row steps are one VALU instruction each: quad_perm [1,0,3,2] and [2,3,0,1] leave every lane of a quad with the quad's
+// value; row_half_mirror (lane i <-> 7 - i of an 8-lane half) then adds the other quad's, row_mirror (i <-> 15 - i) the other half's;
+// the four row results are combined from four v_readlane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) { return x + dpp_mov<CTRL>(x); }
+__device__ __forceinline__ float lane_bcast(float x, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
+#ifdef OCTMAE_WAVE_SUM_SHFL      // the __shfl_xor form of rounds 1-3 (A/B builds only)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+#else
+__device__ __forceinline__ float wave_sum(float v) {
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  v = dpp_add<0x141>(v);
+  v = dpp_add<0x140>(v);
+  return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
+#endif
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
 }
 
 // ---- GELU (timm Mlp act_layer=nn.GELU, exact-erf form x * Phi(x)) ---------------------------------------------

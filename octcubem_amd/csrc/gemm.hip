@@ -367,12 +367,6 @@ constexpr unsigned EPI_OOB = 0x7ffffff0u;
 // Q = false: acc is f32x16[4][2], the 32x32 C layout above.  Q = true: acc is f32x4[8][4], 16 x 16 tiles (a-tile ti, b-tile tj)
 // of v_mfma_f32_16x16x32_bf16: register e of lane (c16 = lane & 15, q4 = lane >> 4) is X[a_base + 16 ti + 4 q4 + e][b_base + 16 tj + c16].
 // Either way a lane holds quads of 4 consecutive a of one output row b, so only the WRITE side of the transpose differs.
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float x) {      // x + (x of the lane CTRL selects), all lanes active
-  const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true);
-  return x + __builtin_bit_cast(float, y);
-}
-
 template <int EPI, bool Q = false, class AccT>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, AccT& acc, int a_base, int b_base, int lane,
                                                   char* wl) {
