@@ -275,7 +275,16 @@ def linear_dgrad_delta(dy: torch.Tensor, w: torch.Tensor, o: torch.Tensor, H: in
     delta = torch.empty((M, H), dtype=F32, device=dy.device)
     args = (w.data_ptr(), dy.data_ptr(), dx.data_ptr(), o.data_ptr(), delta.data_ptr(), M, N, K, w.stride(0), dy.stride(0), K, o.stride(0),
             H, HD, _variant_bits(), _stream())
-    _launch("gemm_dgrad_epi6", 2.0 * K * M * N, 2.0 * (K * N + M * N) + 2.0 * K * M + 2.0 * K * M, lambda: call("octmae_linear_dgrad_delta", *args))
+    rc = [0]
+
+    def run():
+        rc[0] = load().octmae_linear_dgrad_delta(*args)
+
+    _launch("gemm_dgrad_epi6", 2.0 * K * M * N, 2.0 * (K * N + M * N) + 2.0 * K * M + 2.0 * K * M, run)
+    if rc[0] == -2:           # the library's own applicability test said no (e.g. an operand beyond a 32-bit buffer range): plain dgrad
+        return linear_dgrad(dy, w), None
+    if rc[0] != 0:
+        raise RuntimeError(f"octmae_linear_dgrad_delta failed (rc={rc[0]})")
     return dx, delta
 
 
