@@ -7,6 +7,7 @@
 //   bwd bytes/element: 2 (dy) + 4 (x) read, 4 (dx) [+2 (dx bf16)] write; dgamma/dbeta/column sums are
 //   accumulated per lane across the rows a wave walks, reduced over the block in LDS, written as per-block
 //   partials to a caller-provided workspace and folded by a second small kernel (deterministic, no atomics).
+#include <cstdlib>
 #include "common.hpp"
 #include "../../include/octmae.h"
 
@@ -239,9 +240,18 @@ __global__ __launch_bounds__(1024) void ln_bwd_finish_kernel(const float* __rest
   }
 }
 
-static inline int ln_grid(int M) {
+// Grid: whole multiples of the 256 CUs, and FEW of them -- two workgroups per CU forward (8 waves per CU, two rows in flight each), one
+// backward.  With every wave slot filled (2048 / 512 blocks: rounds 1-3) the same kernels read 5.0-5.5 TB/s; with 512 / 256 blocks
+// 5.75-5.99 (round 4, in the step: ln_bwd d512 1034 -> 887 us, d1024 486 -> 455; ln_fwd d512 405 -> 350, d1024 185 -> 173; step
+// +0.55 %): a wave streams one contiguous row at a time, and fewer concurrent row streams keep more DRAM pages open.  Grids that
+// are not multiples of 256 (768, 384, 192) lose to imbalance; one block per CU forward starves the D = 512 rows (3.96 TB/s).
+// OCTMAE_LN_FWD_GRID / OCTMAE_LN_BWD_GRID override the caps for A/B runs (profiles/r04_layernorm_grid.txt).
+static inline int ln_grid(int M, bool bwd = false) {
+  static const int capf = getenv("OCTMAE_LN_FWD_GRID") ? atoi(getenv("OCTMAE_LN_FWD_GRID")) : 512;
+  static const int capb = getenv("OCTMAE_LN_BWD_GRID") ? atoi(getenv("OCTMAE_LN_BWD_GRID")) : 256;
+  const int cap = bwd ? capb : capf;
   int blocks = (M + 3) / 4;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return blocks;
 }
@@ -268,7 +278,7 @@ extern "C" int octmae_layernorm_fwd(const float* x, const float* gamma, const fl
 }
 
 extern "C" int octmae_layernorm_bwd_ws_floats(int M, int D) {
-  int blocks = ln_grid(M);
+  int blocks = ln_grid(M, true);
   if (blocks > 512) blocks = 512;
   return blocks * 3 * D;
 }
@@ -282,7 +292,7 @@ extern "C" int octmae_layernorm_bwd(const void* dy_bf16, const float* x, const f
   const int nc = (D / 4 + 63) / 64;
   const bf16_t* dy = reinterpret_cast<const bf16_t*>(dy_bf16);
   bf16_t* dxb = reinterpret_cast<bf16_t*>(dx_bf16);
-  int blocks = ln_grid(M);
+  int blocks = ln_grid(M, true);
   if (blocks > 512) blocks = 512;
   dim3 grid(blocks), blk(256);
   const bool ws = dxsum != nullptr;
