@@ -360,6 +360,11 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     board_stats = board.stop() if board is not None else None
+    # device memory of this rank's step (caching-allocator peak since process start: the timed steps and the warm-ups are the same
+    # step); what one volume of the micro-batch holds decides whether 128 fits in 288 GB
+    peak_alloc, peak_reserved = torch.cuda.max_memory_allocated(dev), torch.cuda.max_memory_reserved(dev)
+    memory = {"peak_allocated_gib": round(peak_alloc / 2**30, 2), "peak_reserved_gib": round(peak_reserved / 2**30, 2),
+              "micro_batch": mb, "peak_allocated_gib_per_volume_of_micro_batch": round(peak_alloc / 2**30 / mb, 3)}
     kt = ops.KTIMER.summary() if ops.KTIMER is not None else {}
     ops.KTIMER = None
     if comm is not None:
@@ -464,6 +469,7 @@ def main():
                                           "executed_tflops": xfl / (ms * 1e-3) / 1e12, "ms": ms}
         if board_stats is not None:
             out["board"] = board_stats
+        out["memory"] = memory
         if proxy is not None:
             out["per_rank_proxy"] = {"what": "one GPU running the per-rank share of an N-GPU step (256 / N volumes, one micro-batch, "
                                              "no communication): ratio_to_256 = its volumes/s over this line's value",

@@ -38,7 +38,10 @@ int octmae_abi_version(void);
  *   "gemm_mfma16"          0 (default): the 256-tile forward / dgrad GEMMs on v_mfma_f32_32x32x16_bf16 (gemm256p_kernel);
  *                          1: on v_mfma_f32_16x16x32_bf16 (gemm256q_kernel: same tile, staging and epilogues; 3 % faster alone,
  *                          no faster in the training step -- DESIGN.md section 4).  Bit 11 (0x800) of octmae_gemm_bf16's
- *                          `epilogue` argument forces the 32x32x16 form for one call (bits 8-10: tile / main-loop variants) */
+ *                          `epilogue` argument forces the 32x32x16 form for one call (bits 8-10: tile / main-loop variants)
+ *   "wgrad_stagger"        v >= 0 (default 29): split-K weight gradients of >= 8 slices with <= 96 k-tiles each run with slice
+ *                          lengths rising by v / 256 k-tiles per output tile of the launch from one slice to the next, so that the
+ *                          slices' fp32-atomic epilogues follow one another instead of colliding; 0: equal slices */
 int octmae_set_option(const char* key, int value);
 
 /* ---- GEMM with fused epilogues ------------------------------------------------------------------

@@ -54,9 +54,26 @@ struct GemmParams {
   int rows_per_scale;
   int cgroup;              // 256-tile kernels: column tiles (a) per group of the tile order, see tile_coord()
   int hd;                  // EPI_DELTA: head dimension (32 or 64: a head is 4 or 8 lanes of the epilogue's read side)
+  int kstagger;            // split-K: 0 = equal k slices; d > 0 = slice z is d / 256 k-tiles longer than slice z - 1 (split_range)
   int ldc2;                // EPI_DGELU column sums: 0 = C2 is an fp32 [NA] vector (atomics); > 0 = C2 is fp32 [NB / 64][ldc2],
                            // one row of partial sums per 64-row slab, plain stores (folded by a second launch)
 };
+
+// k-tile range of slice kz of an S-way split.  Equal slices end together and their fp32-atomic epilogues (one dword per L2
+// channel and clock, ~1.35 TB/s: 256 workgroups x 256 KiB = 50 us) then run with every k-loop already over.  With kstagger the
+// slice lengths rise linearly with kz -- bound(z) = z ktiles / S - d z (S - z) / 2 -- so the slices finish one after the other and
+// the atomics of slice z overlap the k-loops of slices z + 1 ... (the host picks d = the atomic time of one slice's tiles).
+__device__ __forceinline__ void split_range(const GemmParams& p, int kz, int S, int& kt0, int& kt1) {
+  if (p.kstagger == 0) {
+    kt0 = kz * p.ktiles_per_split;
+    kt1 = kt0 + p.ktiles_per_split;
+    if (kt1 > p.ktiles) kt1 = p.ktiles;
+  } else {
+    auto bound = [&](int z) { return (int)(((long long)z * p.ktiles) / S) - (int)(((long long)p.kstagger * z * (S - z)) >> 9); };
+    kt0 = bound(kz);
+    kt1 = bound(kz + 1);
+  }
+}
 
 // Tile order of the 256-tile kernels.  xcd_remap hands every XCD one contiguous range of t.  Inside a group of `cgroup`
 // column tiles the order is a-fastest (neighbouring workgroups share the activation row panel B), and a group is swept over
@@ -231,9 +248,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const int tb = t / p.tiles_a, ta = t - tb * p.tiles_a;
   const int a0 = ta * TA, b0 = tb * TB;
 
-  const int kt0 = blockIdx.z * p.ktiles_per_split;
-  int kt1 = kt0 + p.ktiles_per_split;
-  if (kt1 > p.ktiles) kt1 = p.ktiles;
+  int kt0, kt1;
+  split_range(p, (int)blockIdx.z, (int)gridDim.z, kt0, kt1);
   const int nk = kt1 - kt0;
 
   f32x16 acc[2][2];
@@ -616,9 +632,8 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const GemmParams p) {
   tile_coord(p, t, ta, tb);
   const int a0 = ta * T2, b0 = tb * T2;
 
-  const int kt0 = kz * p.ktiles_per_split;
-  int kt1 = kt0 + p.ktiles_per_split;
-  if (kt1 > p.ktiles) kt1 = p.ktiles;
+  int kt0, kt1;
+  split_range(p, kz, (int)gridDim.z, kt0, kt1);
   const int nk = kt1 - kt0;
 
   const unsigned a_bytes = (unsigned)((size_t)(A_KS ? p.K : p.NA) * p.lda * 2);
@@ -743,9 +758,8 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const GemmParams p) {
   tile_coord(p, t, ta, tb);
   const int a0 = ta * T2, b0 = tb * T2;
 
-  const int kt0 = kz * p.ktiles_per_split;
-  int kt1 = kt0 + p.ktiles_per_split;
-  if (kt1 > p.ktiles) kt1 = p.ktiles;
+  int kt0, kt1;
+  split_range(p, kz, (int)gridDim.z, kt0, kt1);
   const int nk = kt1 - kt0;
 
   f32x16 acc[4][2];
@@ -1104,6 +1118,13 @@ __global__ __launch_bounds__(512, 1) void gemm256q_kernel(const GemmParams p) {
 // shape, but in the training step on the same box (bench.py --set gemm_mfma16=1 vs 0, three alternations) it is no faster
 // (167.5 vs 167.7 volumes/s; dgrad +3.7 % slower, forward -1 %): profiles/r04_gemm_mfma16_ab.txt.
 std::atomic<int> g_gemm_mfma16{0};
+// Staggered split-K slices of the 256-tile weight-gradient kernel (split_range): v = the length step between neighbouring slices in
+// 1/256 k-tiles PER OUTPUT TILE of the launch (the atomic time of a slice grows with its tile count: 256 KiB at 1.35 TB/s = 0.19 us
+// per tile against 1.7 us per k-tile, i.e. v = 29); 0 = equal slices.  octmae_set_option("wgrad_stagger", v) / OCTMAE_WGRAD_STAGGER.
+// Applied only to splits of >= 8 slices with <= 96 k-tiles each (the [C x C] proj gradients at <= 32 volumes per rank): measured
+// (tools/wgrad_stagger_ab.py, profiles/r04_wgrad_stagger.txt) -9 / -11 % there, and nothing or a loss for the 4- and 5-way splits
+// and for every shape at 128 volumes -- their workgroups do not end together anyway.
+std::atomic<int> g_wgrad_stagger{29};
 
 template <bool A_KS, bool B_KS, int EPI, bool OUT_AB>
 static int launch256(const GemmParams& p, int splitk, hipStream_t st, bool phased, bool mfma16) {
@@ -1219,6 +1240,19 @@ static int gemm_impl(const void* A, const void* B, void* C, void* C2, const floa
   float* dgelu_colsum = (epilogue == EPI_DGELU) ? reinterpret_cast<float*>(C2) : nullptr;
   if (epilogue == EPI_DGELU && !(big && (NA & 7) == 0)) p.C2 = nullptr;
   p.ldc2 = 0; p.hd = 0;
+  p.kstagger = 0;
+  if (big && epilogue == EPI_ACCUM && splitk > 1) {
+    static const int envs = getenv("OCTMAE_WGRAD_STAGGER") ? atoi(getenv("OCTMAE_WGRAD_STAGGER")) : -1;
+    const int v = envs >= 0 ? envs : g_wgrad_stagger.load(std::memory_order_relaxed);
+    if (v > 0 && splitk >= 8 && p.ktiles <= 96 * splitk) {
+      // the shortest slice (ktiles / S - d (S - 1) / 2) keeps at least half the mean length and 8 k-tiles
+      const long long mean_q8 = ((long long)p.ktiles << 8) / splitk;
+      long long d = (long long)v * p.tiles_a * p.tiles_b;
+      const long long dmax = (mean_q8 - (8 << 8) < mean_q8 / 2 ? mean_q8 - (8 << 8) : mean_q8 / 2) * 2 / (splitk - 1);
+      if (d > dmax) d = dmax;
+      if (d > 0) p.kstagger = (int)d;
+    }
+  }
   const int ws_rows = 4 * p.tiles_b;             // 64-row slabs of the 256-tile grid
   if (epilogue == EPI_DGELU && p.C2 != nullptr && colsum_ws != nullptr) { p.C2 = colsum_ws; p.ldc2 = NA; }
 #define OCTMAE_GEMM_CASE(AKS, BKS, E, AB)                                  \
@@ -1285,7 +1319,7 @@ extern "C" int octmae_linear_dgrad_delta(const void* W, const void* dY, void* dX
   p.tiles_a = (K + T2 - 1) / T2; p.tiles_b = (M + T2 - 1) / T2;
   p.cgroup = p.tiles_a;
   if (p.tiles_a >= 16 && p.tiles_a % 4 == 0 && 4 * (size_t)T2 * N * 2 <= (2u << 20)) p.cgroup = 4;
-  p.hd = hd; p.ldc2 = H;
+  p.hd = hd; p.ldc2 = H; p.kstagger = 0;
   auto kern = gemm256p_kernel<true, false, EPI_DELTA, false>;
   static DynLdsOnce once;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -358,7 +358,8 @@ ATTN_BWD_FUSED = {32: True, 64: True}
 def set_option(key: str, value: int) -> int:
     """octmae_set_option: kernel-selection switch for A/B measurements and tests ("attn_bwd_hd32_form" / "attn_bwd_hd64_form":
     1 = one wave per SIMD (default), 0 = the two-waves-per-SIMD kernel; "gemm_mfma16": 1 = 16x16x32 MFMAs in the 256-tile
-    forward / dgrad GEMMs, 0 = 32x32x16 (default: no faster in the step).  Returns the previous value."""
+    forward / dgrad GEMMs, 0 = 32x32x16 (default: no faster in the step); "wgrad_stagger": length step of the k slices of a
+    many-way split-K weight gradient, 0 = equal slices).  Returns the previous value."""
     prev = load().octmae_set_option(key.encode(), int(value))
     if prev < 0:
         raise RuntimeError(f"octmae_set_option: unknown key {key!r}")

@@ -226,6 +226,30 @@ def test_wgrad_large_weight_tile_orders(N, K, M, tile_variant):
         assert rel(gw, ref) < 1e-5
 
 
+@pytest.mark.parametrize("N,K,M,splitk", [(512, 512, 64 * 330 + 17, 16), (1024, 1024, 64 * 200, 16), (512, 256, 64 * 150 + 40, 64),
+                                          (256, 256, 64 * 70, 8), (768, 512, 64 * 90 + 1, 9)])
+@pytest.mark.parametrize("v", [0, 29, 200, 100000])
+def test_wgrad_staggered_split_k_slices(N, K, M, splitk, v):
+    """octmae_set_option("wgrad_stagger", v) (csrc/gemm.hip split_range): the k slices of a split-K weight gradient have linearly
+    rising lengths so that their atomic epilogues do not collide; whatever v (the host clamps the step so that the shortest slice
+    keeps half the mean length and 8 k-tiles), the slices must tile the k range exactly once -- checked against an fp64 product on
+    top of a non-zero accumulator, with a ragged last k-tile, and with the bias-gradient column riding along."""
+    prev = ops.set_option("wgrad_stagger", v)
+    try:
+        g = torch.Generator().manual_seed(N + K + M + splitk)
+        x = bf(torch.randn(M, K, generator=g)).to(DEV)
+        dy = bf(torch.randn(M, N, generator=g)).to(DEV)
+        gw0 = torch.randn(N, K, generator=g).to(DEV)
+        gb0 = torch.randn(N, generator=g).to(DEV)
+        ref = gw0.double() + dy.double().t() @ x.double()
+        gw, gb = gw0.clone(), gb0.clone()
+        ops._gemm(dy, x, gw, N, K, M, N, K, K, 1, 1, ops.EPI_ACCUM, C2=gb, splitk=splitk)
+        assert rel(gw, ref) < 1e-5
+        assert rel(gb, gb0.double() + dy.double().sum(0)) < 2e-5
+    finally:
+        ops.set_option("wgrad_stagger", prev)
+
+
 def test_gemm_rejects_bad_arguments():
     x = torch.zeros(8, 12, dtype=BF16, device=DEV)      # K = 12 not a multiple of 8
     w = torch.zeros(8, 12, dtype=BF16, device=DEV)
