@@ -69,7 +69,7 @@ def cpu_baseline(timed_iters=3):
 
 # bench kernel kind -> kernel name(s) in the PMC file (every 256-tile GEMM runs the phased main loop, gemm256p_kernel, since
 # 993adab; the two-stage gemm256_kernel names stay listed for PMC files collected before that)
-_PMC_KERNEL = {"gemm_wgrad_epi5": ["gemm256p_kernel<true, true, 5, true>", "gemm256_kernel<true, true, 5, true>"],
+_PMC_KERNEL = {"gemm_wgrad_epi5": ["gemm256p_wgrad_pair_kernel", "gemm256p_kernel<true, true, 5, true>", "gemm256_kernel<true, true, 5, true>"],
                "gemm_dgrad_epi0": ["gemm256p_kernel<true, false, 0, false>", "gemm256_kernel<true, false, 0, false>"],
                "gemm_dgrad_epi4": ["gemm256p_kernel<true, false, 4, false>", "gemm256_kernel<true, false, 4, false>"],
                "gemm_dgrad_epi6": ["gemm256p_kernel<true, false, 6, false>"],      # proj dgrad + the attention backward's delta (round 4)

@@ -23,8 +23,8 @@ extern "C" {
 /* The ONE place the ABI number lives: octmae_abi_version() returns it (csrc/probe.hip), octcubem_amd/_lib.py parses it
  * from this header and refuses a library that reports another number, __graft_entry__.build() and the tests compare the two.
  * 4: octmae_attn_bwd_dq_rowconst.  5: octmae_comm_* (RCCL), octmae_attn_bwd_fused + workspace query.  7: octmae_set_option, octmae_scatter_add_rows, octmae_dec_assemble_bwd.
- * 8: octmae_linear_dgrad_delta, octmae_attn_bwd_fused_delta. */
-#define OCTMAE_ABI_VERSION 8
+ * 8: octmae_linear_dgrad_delta, octmae_attn_bwd_fused_delta.  9: octmae_wgrad_accum_pair. */
+#define OCTMAE_ABI_VERSION 9
 int octmae_abi_version(void);
 
 /* Kernel-selection switches for same-process A/B measurements and for tests that cover both forms of a kernel (no reference
@@ -75,6 +75,17 @@ int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2, const floa
 int octmae_dgelu_colsum_ws_rows(int M);
 int octmae_linear_dgrad_dgelu(const void* W, const void* dY, void* dX, const void* pre, float* ws, float* bias_grad,
                               int M, int N, int K, int ldw, int ldy, int ldx, int ldpre, int small_tile, void* stream);
+
+/* Two weight gradients over the SAME token rows in one launch (the fc1 / fc2 and the qkv / proj Linears of a Block; backward of
+ * video_vit.py:114-135 and timm Mlp under autograd):
+ *   gW0 f32 [N0][K0] += dY0[M][N0]^T @ X0[M][K0],   gW1 f32 [N1][K1] += dY1[M][N1]^T @ X1[M][K1]      (dY, X bf16, row-major)
+ *   gB0 / gB1: NULL, or f32 [N] += the column sums of dY (the bias gradient, as epilogue 5 of octmae_gemm_bf16 with C2)
+ * The output tiles of both problems share one split over M: half the fp32-atomic epilogues of two separate launches and k-loops
+ * twice as long.  splitk as in octmae_gemm_bf16.  Returns -2 when either problem does not take the 256-tile kernel (N or K < 256,
+ * an operand beyond a 32-bit buffer range): the caller then issues two octmae_gemm_bf16 calls. */
+int octmae_wgrad_accum_pair(const void* dY0, const void* X0, float* gW0, float* gB0, int N0, int K0, int ldy0, int ldx0, int ldw0,
+                            const void* dY1, const void* X1, float* gW1, float* gB1, int N1, int K1, int ldy1, int ldx1, int ldw1,
+                            int M, int splitk, void* stream);
 
 /* The proj dgrad of an attention block together with the attention backward's per-query constant delta (flash-attn's `dsoftmax_sum`,
  * the backward of video_vit.py:130-134 under autograd):

@@ -735,31 +735,18 @@ __device__ __forceinline__ void glds16(const gi32x4& rsrc, unsigned lds_addr, un
 #pragma clang diagnostic pop
 }
 
+// the tile body: tile t of p, k slice kz of S   (smem: [stage 2][operand 2][half 2] x 16 KiB)
 template <bool A_KS, bool B_KS, int EPI, bool OUT_AB>
-__global__ __launch_bounds__(512, 1) void gemm256p_kernel(const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [stage 2][operand 2][half 2] x 16 KiB
+__device__ __forceinline__ void gemm256p_body(const GemmParams& p, const int t, const int kz, const int S, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wid >> 2, wb = wid & 3;          // wa = 1: the late group (waves 4-7)
-
-  const int nt = p.tiles_a * p.tiles_b;
-  // Split-K launches (weight gradients) are ordered k-slice-major over the XCD-contiguous logical index: the ~32 workgroups
-  // an XCD runs at a time then belong to ONE k slice and to neighbouring tiles, so the operand panels they stream are
-  // shared through that XCD's L2 (with the slice index on blockIdx.z taken as is, every XCD held 8 tiles of EACH slice and
-  // fetched 36 panel streams per 32 workgroups instead of 12-18; the kernel ran at the HBM ceiling, 6 TB/s).
-  int t, kz;
-  if (gridDim.z > 1) {
-    const int L = xcd_remap((int)(blockIdx.x + nt * blockIdx.z), nt * (int)gridDim.z);
-    kz = L / nt; t = L - kz * nt;
-  } else {
-    t = xcd_remap(blockIdx.x, nt); kz = 0;
-  }
   int ta, tb;
   tile_coord(p, t, ta, tb);
   const int a0 = ta * T2, b0 = tb * T2;
 
   int kt0, kt1;
-  split_range(p, kz, (int)gridDim.z, kt0, kt1);
+  split_range(p, kz, S, kt0, kt1);
   const int nk = kt1 - kt0;
 
   f32x16 acc[4][2];
@@ -917,10 +904,47 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const GemmParams p) {
     }
   }
   if (OUT_AB || (p.NA & 7) != 0) {
-    gemm_epilogue<EPI, OUT_AB, 4, 2>(p, acc, a0 + wa * 128, b0 + wb * 64, lane, gridDim.z > 1);
+    gemm_epilogue<EPI, OUT_AB, 4, 2>(p, acc, a0 + wa * 128, b0 + wb * 64, lane, S > 1);
   } else {
     gemm_epilogue_lds<EPI>(p, acc, a0 + wa * 128, b0 + wb * 64, lane, smem + wid * 16384);
   }
+}
+
+template <bool A_KS, bool B_KS, int EPI, bool OUT_AB>
+__global__ __launch_bounds__(512, 1) void gemm256p_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nt = p.tiles_a * p.tiles_b;
+  // Split-K launches (weight gradients) are ordered k-slice-major over the XCD-contiguous logical index: the ~32 workgroups
+  // an XCD runs at a time then belong to ONE k slice and to neighbouring tiles, so the operand panels they stream are
+  // shared through that XCD's L2 (with the slice index on blockIdx.z taken as is, every XCD held 8 tiles of EACH slice and
+  // fetched 36 panel streams per 32 workgroups instead of 12-18; the kernel ran at the HBM ceiling, 6 TB/s).
+  int t, kz;
+  if (gridDim.z > 1) {
+    const int L = xcd_remap((int)(blockIdx.x + nt * blockIdx.z), nt * (int)gridDim.z);
+    kz = L / nt; t = L - kz * nt;
+  } else {
+    t = xcd_remap(blockIdx.x, nt); kz = 0;
+  }
+  gemm256p_body<A_KS, B_KS, EPI, OUT_AB>(p, t, kz, (int)gridDim.z, smem);
+}
+
+// Two weight gradients with the same reduction length (the same token rows) in ONE launch: the tiles of both share the split, so the
+// pair runs tiles0 + tiles1 tiles x S slices where each alone would run tiles x 2 S -- half the fp32-atomic epilogues (256 KiB per
+// workgroup whatever the split) and k-loops twice as long (fc1 + fc2 of a Block: 128 tiles x 2 instead of 2 x (64 x 4)).
+struct GemmPair {
+  GemmParams p0, p1;
+  int nt0, nt1, S;
+};
+__global__ __launch_bounds__(512, 1) void gemm256p_wgrad_pair_kernel(const GemmPair pp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nt = pp.nt0 + pp.nt1;
+  const int L = xcd_remap((int)blockIdx.x, nt * pp.S);          // k-slice-major, as above
+  const int kz = L / nt;
+  int t = L - kz * nt;
+  const bool second = t >= pp.nt0;                              // workgroup-uniform
+  if (second) t -= pp.nt0;
+  if (!second) gemm256p_body<true, true, EPI_ACCUM, true>(pp.p0, t, kz, pp.S, smem);
+  else gemm256p_body<true, true, EPI_ACCUM, true>(pp.p1, t, kz, pp.S, smem);
 }
 
 
@@ -1162,6 +1186,19 @@ static int launch(const GemmParams& p, int splitk, hipStream_t st) {
 
 using namespace octmae;
 
+// GemmParams::kstagger of an S-way split over `ktiles` k-tiles of a launch with `tiles` output tiles (0: equal slices)
+static int wgrad_stagger_for(int ktiles, int splitk, int tiles) {
+  static const int envs = getenv("OCTMAE_WGRAD_STAGGER") ? atoi(getenv("OCTMAE_WGRAD_STAGGER")) : -1;
+  const int v = envs >= 0 ? envs : g_wgrad_stagger.load(std::memory_order_relaxed);
+  if (!(v > 0 && splitk >= 8 && ktiles <= 96 * splitk)) return 0;
+  // the shortest slice (ktiles / S - d (S - 1) / 2) keeps at least half the mean length and 8 k-tiles
+  const long long mean_q8 = ((long long)ktiles << 8) / splitk;
+  long long d = (long long)v * tiles;
+  const long long dmax = (mean_q8 - (8 << 8) < mean_q8 / 2 ? mean_q8 - (8 << 8) : mean_q8 / 2) * 2 / (splitk - 1);
+  if (d > dmax) d = dmax;
+  return d > 0 ? (int)d : 0;
+}
+
 extern "C" int octmae_colsum_accum(const void* in, int in_is_bf16, float* out, int M, int N, int ld, void* stream);
 
 // C[b][a] (+epilogue) = sum_k A[a][k] B[b][k];  see include/octmae.h for the contract.
@@ -1240,19 +1277,7 @@ static int gemm_impl(const void* A, const void* B, void* C, void* C2, const floa
   float* dgelu_colsum = (epilogue == EPI_DGELU) ? reinterpret_cast<float*>(C2) : nullptr;
   if (epilogue == EPI_DGELU && !(big && (NA & 7) == 0)) p.C2 = nullptr;
   p.ldc2 = 0; p.hd = 0;
-  p.kstagger = 0;
-  if (big && epilogue == EPI_ACCUM && splitk > 1) {
-    static const int envs = getenv("OCTMAE_WGRAD_STAGGER") ? atoi(getenv("OCTMAE_WGRAD_STAGGER")) : -1;
-    const int v = envs >= 0 ? envs : g_wgrad_stagger.load(std::memory_order_relaxed);
-    if (v > 0 && splitk >= 8 && p.ktiles <= 96 * splitk) {
-      // the shortest slice (ktiles / S - d (S - 1) / 2) keeps at least half the mean length and 8 k-tiles
-      const long long mean_q8 = ((long long)p.ktiles << 8) / splitk;
-      long long d = (long long)v * p.tiles_a * p.tiles_b;
-      const long long dmax = (mean_q8 - (8 << 8) < mean_q8 / 2 ? mean_q8 - (8 << 8) : mean_q8 / 2) * 2 / (splitk - 1);
-      if (d > dmax) d = dmax;
-      if (d > 0) p.kstagger = (int)d;
-    }
-  }
+  p.kstagger = (big && epilogue == EPI_ACCUM) ? wgrad_stagger_for(p.ktiles, splitk, p.tiles_a * p.tiles_b) : 0;
   const int ws_rows = 4 * p.tiles_b;             // 64-row slabs of the 256-tile grid
   if (epilogue == EPI_DGELU && p.C2 != nullptr && colsum_ws != nullptr) { p.C2 = colsum_ws; p.ldc2 = NA; }
 #define OCTMAE_GEMM_CASE(AKS, BKS, E, AB)                                  \
@@ -1282,6 +1307,52 @@ static int gemm_impl(const void* A, const void* B, void* C, void* C2, const floa
   OCTMAE_GEMM_CASE(1, 1, EPI_ACCUM, true)
 #undef OCTMAE_GEMM_CASE
   return -2;  // layout / epilogue combination not built
+}
+
+// gW0[N0][K0] += dY0[M][N0]^T X0[M][K0]  and  gW1[N1][K1] += dY1[M][N1]^T X1[M][K1]  (gB: fp32 [N] += column sums of dY, or NULL) in
+// one launch of gemm256p_wgrad_pair_kernel.  Returns -2 when either problem does not take the 256-tile kernel (the caller then
+// issues two octmae_gemm_bf16 calls).
+extern "C" int octmae_wgrad_accum_pair(const void* dY0, const void* X0, float* gW0, float* gB0, int N0, int K0, int ldy0, int ldx0, int ldw0,
+                                       const void* dY1, const void* X1, float* gW1, float* gB1, int N1, int K1, int ldy1, int ldx1, int ldw1,
+                                       int M, int splitk, void* stream) {
+  OCTMAE_CHECK_ARG(dY0 && X0 && gW0 && dY1 && X1 && gW1 && M > 0 && N0 > 0 && K0 > 0 && N1 > 0 && K1 > 0);
+  OCTMAE_CHECK_ARG((ldy0 % 8) == 0 && (ldx0 % 8) == 0 && (ldy1 % 8) == 0 && (ldx1 % 8) == 0);
+  OCTMAE_CHECK_ARG((N0 % 8) == 0 && (K0 % 8) == 0 && (N1 % 8) == 0 && (K1 % 8) == 0);
+  GemmPair pp;
+  auto fill = [&](GemmParams& p, const void* dY, const void* X, float* gW, float* gB, int N, int K, int ldy, int ldx, int ldw) {
+    const size_t a_bytes = (size_t)M * ldy * 2, b_bytes = (size_t)M * ldx * 2;
+    if (!(N >= T2 && K >= T2 && a_bytes < 0xFFF00000ull && b_bytes < 0xFFF00000ull)) return false;
+    p.A = reinterpret_cast<const bf16_t*>(dY); p.B = reinterpret_cast<const bf16_t*>(X);
+    p.C = gW; p.C2 = gB; p.bias = nullptr; p.aux = nullptr; p.rowscale = nullptr; p.rows_per_scale = 1;
+    p.NA = N; p.NB = K; p.K = M; p.lda = ldy; p.ldb = ldx; p.ldc = ldw; p.ldaux = 0;
+    p.ktiles = (M + TK - 1) / TK;
+    p.tiles_a = (N + T2 - 1) / T2; p.tiles_b = (K + T2 - 1) / T2;
+    p.cgroup = p.tiles_a;
+    if (p.tiles_a * p.tiles_b > 32) {          // as in gemm_impl: a compact rectangle of tiles per XCD
+      int c = 32 / p.tiles_b;
+      if (c < 1) c = 1;
+      while (c > 1 && p.tiles_a % c != 0) --c;
+      p.cgroup = c;
+    }
+    p.ldc2 = 0; p.hd = 0; p.kstagger = 0;
+    return true;
+  };
+  if (!fill(pp.p0, dY0, X0, gW0, gB0, N0, K0, ldy0, ldx0, ldw0) || !fill(pp.p1, dY1, X1, gW1, gB1, N1, K1, ldy1, ldx1, ldw1)) return -2;
+  const int ktiles = pp.p0.ktiles;
+  if (splitk < 1) splitk = 1;
+  if (splitk > ktiles) splitk = ktiles;
+  const int per = (ktiles + splitk - 1) / splitk;
+  splitk = (ktiles + per - 1) / per;
+  pp.p0.ktiles_per_split = pp.p1.ktiles_per_split = per;
+  pp.nt0 = pp.p0.tiles_a * pp.p0.tiles_b; pp.nt1 = pp.p1.tiles_a * pp.p1.tiles_b; pp.S = splitk;
+  pp.p0.kstagger = pp.p1.kstagger = wgrad_stagger_for(ktiles, splitk, pp.nt0 + pp.nt1);
+  auto kern = gemm256p_wgrad_pair_kernel;
+  static DynLdsOnce once;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (int rc = once.ensure(reinterpret_cast<const void*>(kern), 4 * TILE2_BYTES)) return rc;
+  hipLaunchKernelGGL(kern, dim3((pp.nt0 + pp.nt1) * splitk, 1, 1), dim3(512), 4 * TILE2_BYTES, st, pp);
+  OCTMAE_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,

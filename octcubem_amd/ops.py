@@ -309,6 +309,43 @@ def linear_wgrad_accum(dy: torch.Tensor, x: torch.Tensor, gw: torch.Tensor, gb: 
           splitk=_splitk_for(tiles, ktiles, 256 if big else 1024))
 
 
+WGRAD_PAIR = True     # fc1 + fc2 and qkv + proj weight gradients of a Block as one launch each (octmae_wgrad_accum_pair)
+
+
+def linear_wgrad_accum_pair(first, second):
+    """Two linear_wgrad_accum calls over the same token rows -- (dy, x, gw, gb) each -- as ONE launch: the tiles of both outputs
+    share the split over the rows, so there are half as many fp32-atomic epilogues and the k-loops are twice as long (measured on
+    the combined shape, tools/wgrad_group_bound.py: -12 ... -15 % at 32 volumes, -2 ... -7 % at 128).  Falls back to two launches when
+    the library says the pair does not apply (-2) or WGRAD_PAIR is off."""
+    (dy0, x0, gw0, gb0), (dy1, x1, gw1, gb1) = first, second
+    M = dy0.shape[0]
+    ok = (WGRAD_PAIR and not FORCE_SMALL_TILE and dy1.shape[0] == M and x0.shape[0] == M and x1.shape[0] == M
+          and min(dy0.shape[1], x0.shape[1], dy1.shape[1], x1.shape[1]) >= 256)
+    if ok:
+        tiles = sum(((dy.shape[1] + 255) // 256) * ((x.shape[1] + 255) // 256) for dy, x in ((dy0, x0), (dy1, x1)))
+        rc = [0]
+        args = []
+        for dy, x, gw, gb in (first, second):
+            for t_, dt_, nm_ in ((dy, BF16, "dy"), (x, BF16, "x"), (gw, F32, "gw")):       # rows may be slices of wider tensors
+                if not (t_.is_cuda and t_.dtype == dt_ and t_.dim() == 2 and t_.stride(1) == 1):
+                    raise RuntimeError(f"linear_wgrad_accum_pair: {nm_} must be a GPU {dt_} matrix with contiguous rows")
+            args += [dy.data_ptr(), x.data_ptr(), gw.data_ptr(), _p(gb), dy.shape[1], x.shape[1], dy.stride(0), x.stride(0), gw.stride(0)]
+        args += [M, _splitk_for(tiles, (M + 63) // 64, 256), _stream()]
+
+        def run():
+            rc[0] = load().octmae_wgrad_accum_pair(*args)
+
+        fl = 2.0 * M * (dy0.shape[1] * x0.shape[1] + dy1.shape[1] * x1.shape[1])
+        nb = 2.0 * M * (dy0.shape[1] + x0.shape[1] + dy1.shape[1] + x1.shape[1]) + 4.0 * (gw0.numel() + gw1.numel())
+        _launch("gemm_wgrad_epi5", fl, nb, run)
+        if rc[0] == 0:
+            return
+        if rc[0] != -2:
+            raise RuntimeError(f"octmae_wgrad_accum_pair failed (rc={rc[0]})")
+    linear_wgrad_accum(dy0, x0, gw0, gb0)
+    linear_wgrad_accum(dy1, x1, gw1, gb1)
+
+
 def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float):
     M, D = x.shape
     y = torch.empty((M, D), dtype=BF16, device=x.device)
@@ -675,9 +712,8 @@ class BlockFn(torch.autograd.Function):
             if gb2 is not None:
                 colsum_accum(d3, gb2)
         # ---- MLP
-        linear_wgrad_accum(d3b, act, gw2)
         dpre = linear_dgrad(d3b, w2, pre=pre, colsum=gb1)          # GELU' and fc1's bias gradient in the epilogue
-        linear_wgrad_accum(dpre, y2, gw1)
+        linear_wgrad_accum_pair((d3b, act, gw2, None), (dpre, y2, gw1, None))
         dy2 = linear_dgrad(dpre, w1)
         # ---- LN2 backward + residual add + bf16 copy + proj bias gradient
         if ctx.final_residual:
@@ -692,13 +728,12 @@ class BlockFn(torch.autograd.Function):
             if gbproj is not None:
                 colsum_accum(dx2b, gbproj)
         # ---- attention
-        linear_wgrad_accum(dx2b, o, gwproj)
         fused_bwd = ATTN_BWD_FUSED[HD]
         do, delta = linear_dgrad_delta(dx2b, wproj, o, H, HD) if fused_bwd else (linear_dgrad(dx2b, wproj), None)
         dqkv = attn_bwd(qkv, o, do, lse, Bn, N, H, HD, scale, delta=delta)
         # the qkv bias gradient rides in the weight-gradient GEMM (column sums of its dY operand); fusing it into the attention
         # backward kernels had been measured and dropped (+10..25 % on their main loops for a 2 % pass)
-        linear_wgrad_accum(dqkv, y1, gwqkv, gbqkv)
+        linear_wgrad_accum_pair((dx2b, o, gwproj, None), (dqkv, y1, gwqkv, gbqkv))
         dy1 = linear_dgrad(dqkv, wqkv)
         # ---- LN1 backward + residual add; its bf16 copy / column sums are what the previous Block's backward needs
         colsum = torch.zeros(C, dtype=F32, device=dx3.device)

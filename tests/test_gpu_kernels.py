@@ -250,6 +250,32 @@ def test_wgrad_staggered_split_k_slices(N, K, M, splitk, v):
         ops.set_option("wgrad_stagger", prev)
 
 
+@pytest.mark.parametrize("M,first,second", [(64 * 37 + 5, (1024, 256), (256, 1024)),      # fc2 / fc1 of a Block (C = 256)
+                                            (64 * 60, (512, 512), (1536, 512)),           # proj / qkv with the qkv bias gradient
+                                            (64 * 200 + 63, (2048, 512), (512, 2048)),    # 32 tiles, split 8
+                                            (700, (256, 256), (768, 256)),
+                                            (900, (128, 512), (512, 128))])               # not applicable: two launches
+def test_wgrad_pair_launch(M, first, second):
+    """octmae_wgrad_accum_pair (ops.linear_wgrad_accum_pair): two weight gradients over the same rows in one launch must equal the
+    two separate launches' results (fp64 reference, non-zero accumulators, the bias-gradient column on the second problem only,
+    operands that are column slices of wider tensors)."""
+    g = torch.Generator().manual_seed(M + first[0] + second[1])
+    probs, refs = [], []
+    for i, (N, K) in enumerate((first, second)):
+        dyw = bf(torch.randn(M, N + 16, generator=g)).to(DEV)
+        xw = bf(torch.randn(M, K + 8, generator=g)).to(DEV)
+        dy, x = dyw[:, 8:N + 8], xw[:, :K]                      # leading dimensions != widths
+        gw = torch.randn(N, K, generator=g).to(DEV)
+        gb = torch.randn(N, generator=g).to(DEV) if i == 1 else None
+        refs.append((gw.double() + dy.double().t() @ x.double(), None if gb is None else gb.double() + dy.double().sum(0)))
+        probs.append((dy, x, gw, gb))
+    ops.linear_wgrad_accum_pair(probs[0], probs[1])
+    for (dy, x, gw, gb), (rw, rb) in zip(probs, refs):
+        assert rel(gw, rw) < 1e-5
+        if gb is not None:
+            assert rel(gb, rb) < 2e-5
+
+
 def test_gemm_rejects_bad_arguments():
     x = torch.zeros(8, 12, dtype=BF16, device=DEV)      # K = 12 not a multiple of 8
     w = torch.zeros(8, 12, dtype=BF16, device=DEV)
