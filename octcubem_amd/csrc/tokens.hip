@@ -11,7 +11,23 @@ namespace octmae {
 // fp32 -> bf16 cast (weight arena refresh, gradient cast).  8 elements per thread.
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
   const size_t n8 = n >> 3;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+  // four independent 32-byte loads per lane in flight (a grid-stride apart), then the four stores
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n8; i += 4 * stride) {
+    f32x4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = *reinterpret_cast<const f32x4*>(src + 8 * (i + u * stride));
+      b[u] = *reinterpret_cast<const f32x4*>(src + 8 * (i + u * stride) + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      u32x4 w = {pack2bf(a[u][0], a[u][1]), pack2bf(a[u][2], a[u][3]), pack2bf(b[u][0], b[u][1]), pack2bf(b[u][2], b[u][3])};
+      *reinterpret_cast<u32x4*>(dst + 8 * (i + u * stride)) = w;
+    }
+  }
+  for (; i < n8; i += stride) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(src + 8 * i);
     const f32x4 b = *reinterpret_cast<const f32x4*>(src + 8 * i + 4);
     u32x4 w = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
@@ -403,7 +419,10 @@ using namespace octmae;
 extern "C" int octmae_cast_f32_bf16(const float* src, void* dst_bf16, long long n, void* stream) {
   OCTMAE_CHECK_ARG(src && dst_bf16 && n >= 0);
   if (n == 0) return 0;
-  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for((size_t)n / 8 + 1)), dim3(256), 0,
+  // 512 workgroups (two per CU, four loads in flight per lane): 5.4 TB/s on the 332 M-parameter arena against 4.8-5.2 with 1024-4096
+  // workgroups and 2.7-4.0 for the un-unrolled loop on 4096 (tools/cast_bench.py) -- the "few row streams" rule of layernorm.hip
+  static const int cast_cap = getenv("OCTMAE_CAST_GRID") ? atoi(getenv("OCTMAE_CAST_GRID")) : 512;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for((size_t)n / 8 + 1, 256, cast_cap)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), src, reinterpret_cast<bf16_t*>(dst_bf16), (size_t)n);
   OCTMAE_LAUNCH_CHECK();
   return 0;
