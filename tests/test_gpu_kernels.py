@@ -276,6 +276,41 @@ def test_wgrad_pair_launch(M, first, second):
             assert rel(gb, rb) < 2e-5
 
 
+def _pair_call(probs, M, splitk):
+    from octcubem_amd._lib import load
+    args = []
+    for dy, x, gw, gb in probs:
+        args += [dy.data_ptr(), x.data_ptr(), gw.data_ptr(), 0 if gb is None else gb.data_ptr(), dy.shape[1], x.shape[1],
+                 dy.stride(0), x.stride(0), gw.stride(0)]
+    return load().octmae_wgrad_accum_pair(*args, M, splitk, torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("M", [64 * 21 + 9, 64 * 64])
+def test_wgrad_pair_is_bit_identical_to_single_launches_without_split(M):
+    """Without a split there are no atomics: the pair kernel runs the same tile body (gemm256p_body) on the same k order, so each of
+    its two results must equal the single launch's bit for bit -- also for the bias-gradient column sums of a one-column-tile problem."""
+    g = torch.Generator().manual_seed(M)
+    probs = []
+    for N, K in ((768, 256), (256, 512)):
+        dy = bf(torch.randn(M, N, generator=g)).to(DEV); x = bf(torch.randn(M, K, generator=g)).to(DEV)
+        probs.append((dy, x, torch.randn(N, K, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)))
+    single = []
+    for dy, x, gw, gb in probs:
+        gw1 = gw.clone(); gb1 = gb.clone()
+        ops._gemm(dy, x, gw1, dy.shape[1], x.shape[1], M, dy.stride(0), x.stride(0), gw1.stride(0), 1, 1, ops.EPI_ACCUM, C2=gb1, splitk=1)
+        single.append((gw1, gb1))
+    assert _pair_call(probs, M, 1) == 0
+    for (dy, x, gw, gb), (gw1, gb1) in zip(probs, single):
+        assert torch.equal(gw, gw1)
+        if x.shape[1] <= 256:                  # one tile along b: a single workgroup per a-range adds to each entry (no atomic order)
+            assert torch.equal(gb, gb1)
+        else:
+            assert rel(gb, gb1) < 1e-6
+    # a problem that does not take the 256-tile kernel: -2, nothing written
+    small = (probs[0][0][:, :128], probs[0][1], torch.zeros(128, 256, device=DEV), None)
+    assert _pair_call([small, probs[1]], M, 1) == -2
+
+
 def test_gemm_rejects_bad_arguments():
     x = torch.zeros(8, 12, dtype=BF16, device=DEV)      # K = 12 not a multiple of 8
     w = torch.zeros(8, 12, dtype=BF16, device=DEV)

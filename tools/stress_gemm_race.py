@@ -22,6 +22,19 @@ while time.time() - t0 < budget:
             ops._gemm(dy, x, gw, N, K, M, N, K, K, 1, 1, ops.EPI_ACCUM, splitk=1)
             outs[name] = (ops.linear_fwd(x, w, None, "bf16"), ops.linear_dgrad(dy, w), ops.linear_dgrad(dy, w, pre=pre), gw)
         ops.FORCE_TWO_STAGE = ops.FORCE_PHASED = False
+        if N >= 256 and K >= 256:
+            # the paired weight-gradient launch without a split (no atomics): bit-identical to the single launches, twice over
+            from octcubem_amd._lib import load
+            gwa, gwb = torch.zeros(N, K, device="cuda"), torch.zeros(K, N, device="cuda")
+            a = [dy.data_ptr(), x.data_ptr(), gwa.data_ptr(), 0, N, K, N, K, K, x.data_ptr(), dy.data_ptr(), gwb.data_ptr(), 0, K, N, K, N, N]
+            rc = load().octmae_wgrad_accum_pair(*a, M, 1, torch.cuda.current_stream().cuda_stream)
+            gwb1 = torch.zeros(K, N, device="cuda")
+            ops._gemm(x, dy, gwb1, K, N, M, K, N, N, 1, 1, ops.EPI_ACCUM, splitk=1)
+            for a_, b_ in ((gwa, outs["pha"][3]), (gwb, gwb1)):
+                n += 1
+                if rc != 0 or not torch.equal(a_, b_):
+                    bad += 1
+                    print("MISMATCH pair", (M, K, N), rc, flush=True)
         for a, b in zip(outs["two"], outs["pha"]):
             n += 1
             if not torch.equal(a, b):
