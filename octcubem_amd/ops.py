@@ -320,7 +320,9 @@ def linear_wgrad_accum_pair(first, second):
     (dy0, x0, gw0, gb0), (dy1, x1, gw1, gb1) = first, second
     M = dy0.shape[0]
     ok = (WGRAD_PAIR and not FORCE_SMALL_TILE and dy1.shape[0] == M and x0.shape[0] == M and x1.shape[0] == M
-          and min(dy0.shape[1], x0.shape[1], dy1.shape[1], x1.shape[1]) >= 256)
+          and min(dy0.shape[1], x0.shape[1], dy1.shape[1], x1.shape[1]) >= 256
+          # the library's own applicability test (each operand inside one 32-bit buffer descriptor), so that -2 is not met here
+          and 2 * M * max(dy0.stride(0), x0.stride(0), dy1.stride(0), x1.stride(0)) < 0xFFF00000)
     if ok:
         tiles = sum(((dy.shape[1] + 255) // 256) * ((x.shape[1] + 255) // 256) for dy, x in ((dy0, x0), (dy1, x1)))
         rc = [0]
