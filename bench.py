@@ -29,6 +29,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails otherwise); the GPU boxes export it already --
+# set before anything initialises HIP, and only if the launcher did not choose a value itself
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
