@@ -87,6 +87,12 @@ int octmae_wgrad_accum_pair(const void* dY0, const void* X0, float* gW0, float* 
                             const void* dY1, const void* X1, float* gW1, float* gB1, int N1, int K1, int ldy1, int ldx1, int ldw1,
                             int M, int splitk, void* stream);
 
+/* Planning arithmetic of the split-K weight gradients, host side only (no GPU is touched; for tests): the number of k slices a launch of
+ * `tiles` output tiles over M token rows uses for a requested splitk (-> *slices), the first 64-row k-tile of every slice
+ * (bounds[0 .. *slices], bounds[*slices] = ceil(M / 64); room for splitk + 1 ints), and -- the return value -- the length step between
+ * neighbouring slices in 1/256 k-tiles (0 = equal slices; see "wgrad_stagger" above).  Negative: argument error. */
+int octmae_wgrad_split_plan(int M, int splitk, int tiles, int* slices, int* bounds);
+
 /* The proj dgrad of an attention block together with the attention backward's per-query constant delta (flash-attn's `dsoftmax_sum`,
  * the backward of video_vit.py:130-134 under autograd):
  *   dX bf16 [M][K] = dY[M][N] @ W[N][K],   delta f32 [M][H] = -sum over each head's hd columns of dX * O     (O bf16 [M][K], K = H hd)

@@ -38,6 +38,7 @@ SIGNATURES = {
     "octmae_dgelu_colsum_ws_rows": [_i],
     "octmae_linear_dgrad_dgelu": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "octmae_linear_dgrad_delta": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "octmae_wgrad_split_plan": [_i, _i, _i, _vp, _vp],
     "octmae_wgrad_accum_pair": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "octmae_patch_gather": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "octmae_enc_assemble": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

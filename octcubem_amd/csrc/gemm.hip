@@ -63,16 +63,19 @@ struct GemmParams {
 // channel and clock, ~1.35 TB/s: 256 workgroups x 256 KiB = 50 us) then run with every k-loop already over.  With kstagger the
 // slice lengths rise linearly with kz -- bound(z) = z ktiles / S - d z (S - z) / 2 -- so the slices finish one after the other and
 // the atomics of slice z overlap the k-loops of slices z + 1 ... (the host picks d = the atomic time of one slice's tiles).
-__device__ __forceinline__ void split_range(const GemmParams& p, int kz, int S, int& kt0, int& kt1) {
-  if (p.kstagger == 0) {
-    kt0 = kz * p.ktiles_per_split;
-    kt1 = kt0 + p.ktiles_per_split;
-    if (kt1 > p.ktiles) kt1 = p.ktiles;
+__host__ __device__ __forceinline__ void split_range_of(int ktiles, int ktiles_per_split, int kstagger, int kz, int S, int& kt0, int& kt1) {
+  if (kstagger == 0) {
+    kt0 = kz * ktiles_per_split;
+    kt1 = kt0 + ktiles_per_split;
+    if (kt1 > ktiles) kt1 = ktiles;
   } else {
-    auto bound = [&](int z) { return (int)(((long long)z * p.ktiles) / S) - (int)(((long long)p.kstagger * z * (S - z)) >> 9); };
+    auto bound = [&](int z) { return (int)(((long long)z * ktiles) / S) - (int)(((long long)kstagger * z * (S - z)) >> 9); };
     kt0 = bound(kz);
     kt1 = bound(kz + 1);
   }
+}
+__device__ __forceinline__ void split_range(const GemmParams& p, int kz, int S, int& kt0, int& kt1) {
+  split_range_of(p.ktiles, p.ktiles_per_split, p.kstagger, kz, S, kt0, kt1);
 }
 
 // Tile order of the 256-tile kernels.  xcd_remap hands every XCD one contiguous range of t.  Inside a group of `cgroup`
@@ -1307,6 +1310,28 @@ static int gemm_impl(const void* A, const void* B, void* C, void* C2, const floa
   OCTMAE_GEMM_CASE(1, 1, EPI_ACCUM, true)
 #undef OCTMAE_GEMM_CASE
   return -2;  // layout / epilogue combination not built
+}
+
+// The split a weight-gradient launch of `tiles` 256 x 256 output tiles over M rows would use for a requested `splitk` (host-side
+// arithmetic only; no GPU is touched): writes the number of slices to *slices and the first k-tile of slice z to bounds[z]
+// (z = 0 .. slices, bounds[slices] = the number of 64-row k-tiles), and returns the length step kstagger (1/256 k-tiles; 0 = equal
+// slices).  `bounds` needs splitk + 1 ints.  For tests of the planning code (tests/test_cpu_host.py).
+extern "C" int octmae_wgrad_split_plan(int M, int splitk, int tiles, int* slices, int* bounds) {
+  OCTMAE_CHECK_ARG(M > 0 && tiles > 0 && slices && bounds);
+  const int ktiles = (M + TK - 1) / TK;
+  if (splitk < 1) splitk = 1;
+  if (splitk > ktiles) splitk = ktiles;
+  const int per = (ktiles + splitk - 1) / splitk;
+  splitk = (ktiles + per - 1) / per;
+  const int d = wgrad_stagger_for(ktiles, splitk, tiles);
+  *slices = splitk;
+  for (int z = 0; z < splitk; ++z) {
+    int a, b;
+    split_range_of(ktiles, per, d, z, splitk, a, b);
+    bounds[z] = a;
+    bounds[z + 1] = b;
+  }
+  return d;
 }
 
 // gW0[N0][K0] += dY0[M][N0]^T X0[M][K0]  and  gW1[N1][K1] += dY1[M][N1]^T X1[M][K1]  (gB: fp32 [N] += column sums of dY, or NULL) in

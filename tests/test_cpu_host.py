@@ -43,6 +43,53 @@ def test_argument_errors_are_reported_without_a_gpu():
         _lib.call("octmae_cast_f32_bf16", None, None, 8, None)
 
 
+def test_weight_gradient_split_plan_tiles_the_rows_exactly_once():
+    """octmae_wgrad_split_plan (csrc/gemm.hip: the host-side copy of the arithmetic the weight-gradient kernels run, split_range_of +
+    wgrad_stagger_for): whatever the row count, the requested split, the tile count and the stagger option, the k slices must
+    cover [0, ceil(M / 64)) contiguously, none empty; staggered slices rise linearly and the shortest keeps at least half the mean
+    length and 8 k-tiles; the rule applies only to >= 8 slices of <= 96 k-tiles; option 0 switches it off."""
+    from octcubem_amd import _lib
+    lib = _lib.load()
+    import random
+    rng = random.Random(4)
+    prev = lib.octmae_set_option(b"wgrad_stagger", 29)
+    try:
+        seen_staggered = 0
+        for v in (29, 0, 200, 100000):
+            assert lib.octmae_set_option(b"wgrad_stagger", v) >= 0
+            for _ in range(400):
+                M = rng.choice([1, 63, 64, 65, 700, 40992, 163968, 655488, rng.randrange(1, 700000)])
+                splitk = rng.choice([1, 2, 3, 4, 5, 8, 9, 16, 21, 64, rng.randrange(1, 300)])
+                tiles = rng.choice([1, 4, 12, 16, 48, 64, 128])
+                slices = ctypes.c_int(0)
+                bounds = (ctypes.c_int * (splitk + 2))()
+                d = lib.octmae_wgrad_split_plan(M, splitk, tiles, ctypes.byref(slices), bounds)
+                S, ktiles = slices.value, (M + 63) // 64
+                b = list(bounds[:S + 1])
+                assert 1 <= S <= max(1, min(splitk, ktiles)), (M, splitk, S)
+                assert b[0] == 0 and b[-1] == ktiles, (M, splitk, tiles, v, b)
+                lens = [b[i + 1] - b[i] for i in range(S)]
+                assert min(lens) >= 1, (M, splitk, tiles, v, lens)
+                if d == 0:                                   # equal slices: all but the last have the same length
+                    assert len(set(lens[:-1])) <= 1 and lens[-1] <= lens[0]
+                else:
+                    seen_staggered += 1
+                    assert v > 0 and S >= 8 and ktiles <= 96 * S
+                    mean = ktiles / S
+                    assert min(lens) >= min(mean / 2, mean - 8) - 1.01 and min(lens) >= 7, (lens, mean)
+                    # rising by d / 256 k-tiles per slice; each bound carries two floors (error in (-1, 1)), a length two bounds,
+                    # a difference of lengths three
+                    step = d / 256.0
+                    assert all(abs((lens[i + 1] - lens[i]) - step) < 4.0 for i in range(S - 1)), (lens, step)
+                    assert abs((lens[-1] - lens[0]) - step * (S - 1)) < 4.0, (lens, step)
+                if v == 0:
+                    assert d == 0
+        assert seen_staggered > 50
+        assert lib.octmae_wgrad_split_plan(0, 4, 16, None, None) == -1
+    finally:
+        lib.octmae_set_option(b"wgrad_stagger", prev)
+
+
 def test_model_contract_and_state_dict_keys():
     from octcubem_amd import models_mae
     from functools import partial
