@@ -313,3 +313,31 @@ class MetricLogger:
             end = time.time()
         if is_main_process():
             print(f"{header} Total time: {datetime.timedelta(seconds=int(time.time() - start))}", flush=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# checkpoint positional tables, as OCTCube/util/misc.py has them (the functions inference_utils.py and the fine-tune drivers import
+# from there; util/pos_embed.py holds a DIFFERENT interpolate_pos_embed, which also resizes ``pos_embed_spatial`` -- pos_embed.py here)
+# ------------------------------------------------------------------------------------------------
+def interpolate_pos_embed(model, checkpoint_model):
+    """OCTCube/util/misc.py:1159-1222: bicubic resize of ``pos_embed`` and ``decoder_pos_embed`` (extra tokens kept) to the model's
+    patch grid.  ``pos_embed_spatial`` is NOT touched by this variant: a separable-table checkpoint of another spatial grid then fails
+    the strict load that follows, exactly as in the reference."""
+    from .pos_embed import _resize_square
+    for name in ("pos_embed", "decoder_pos_embed"):
+        if name not in checkpoint_model:
+            continue
+        ck = checkpoint_model[name]
+        num_patches = model.patch_embed.num_patches
+        num_extra = getattr(model, name).shape[-2] - num_patches
+        orig_size = int((ck.shape[-2] - num_extra) ** 0.5)
+        new_size = int(num_patches ** 0.5)
+        if orig_size != new_size:
+            print("Position interpolate from %dx%d to %dx%d" % (orig_size, orig_size, new_size, new_size))
+            checkpoint_model[name] = torch.cat((ck[:, :num_extra], _resize_square(ck[:, num_extra:], orig_size, new_size)), dim=1)
+
+
+def interpolate_temporal_pos_embed(model, checkpoint_model, smaller_interpolate_type="interp"):
+    """OCTCube/util/misc.py:1225-1258 (the same function as util/pos_embed.py's)."""
+    from .pos_embed import interpolate_temporal_pos_embed as f
+    return f(model, checkpoint_model, smaller_interpolate_type)
