@@ -309,7 +309,8 @@ def linear_wgrad_accum(dy: torch.Tensor, x: torch.Tensor, gw: torch.Tensor, gb: 
           splitk=_splitk_for(tiles, ktiles, 256 if big else 1024))
 
 
-WGRAD_PAIR = True     # fc1 + fc2 and qkv + proj weight gradients of a Block as one launch each (octmae_wgrad_accum_pair)
+# fc1 + fc2 and qkv + proj weight gradients of a Block as one launch each (octmae_wgrad_accum_pair); OCTMAE_WGRAD_PAIR=0: same-box A/B
+WGRAD_PAIR = os.environ.get("OCTMAE_WGRAD_PAIR", "1") != "0"
 
 
 def linear_wgrad_accum_pair(first, second):
