@@ -6,13 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from octcubem_amd import ops
 
-_argv, sys.argv = sys.argv, [sys.argv[0]]
-import importlib.util
-spec = importlib.util.spec_from_file_location("pp", os.path.join(os.path.dirname(os.path.abspath(__file__)), "power_probe.py"))
-src = open(spec.origin).read().split("\ng = torch.Generator")[0]          # the helpers only, not the probe's own main part
-pp = {"__file__": spec.origin, "__name__": "power_probe_helpers"}
-exec(compile(src, spec.origin, "exec"), pp)
-loop = pp["loop"]
+from power_probe import loop
 
 g = torch.Generator(device="cuda").manual_seed(0)
 B = 128
