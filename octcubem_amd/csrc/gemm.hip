@@ -379,6 +379,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* base, int
                                            __builtin_amdgcn_readfirstlane(rows * ld * esize), 0x00020000);
 }
 constexpr unsigned EPI_OOB = 0x7ffffff0u;
+#ifndef EPI_LOAD_AUX
+#define EPI_LOAD_AUX 0    // cache policy of the epilogues' own streaming reads (residual stream, pre-activation, attention output)
+#endif
 #ifndef EPI_STORE_AUX
 #define EPI_STORE_AUX 3   // sc0 nt: streaming stores (outputs are >= 100 MB and not re-read before they leave the L2); measured -5..6 % on the bf16 / GELU forwards
 #endif   // byte offset past any num_records above: masks a lane whose columns are >= NA
@@ -403,7 +406,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, AccT& acc
       const __amdgpu_buffer_rsrc_t rx = epi_rsrc(p.aux, b_base, p.NB, p.ldaux, 2);
       const unsigned o_aux = a_ok ? (unsigned)(rrow * p.ldaux + a) * 2u : EPI_OOB;
 #pragma unroll
-      for (int it = 0; it < 16; ++it) prev[it] = __builtin_amdgcn_raw_buffer_load_b128(rx, o_aux + it * 4 * p.ldaux * 2, 0, 0);
+      for (int it = 0; it < 16; ++it) prev[it] = __builtin_amdgcn_raw_buffer_load_b128(rx, o_aux + it * 4 * p.ldaux * 2, 0, EPI_LOAD_AUX);
     }
     // All 16 bias quads of the lane are requested together before the first store.  vmcnt retires in order: a bias load
     // issued after stores -- the second pass of EPI_GELU reloaded them -- waits for every store ahead of it to be
@@ -527,7 +530,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, AccT& acc
       const int a = a_base + half * 64 + rc * 4;
       const unsigned o_aux = a < p.NA ? (unsigned)(rrow * p.ldaux + a) * 4u : EPI_OOB;
 #pragma unroll
-      for (int it = 0; it < 16; ++it) resv[half][it] = __builtin_amdgcn_raw_buffer_load_b128(rx, o_aux + it * 4 * p.ldaux * 4, 0, 0);
+      for (int it = 0; it < 16; ++it) resv[half][it] = __builtin_amdgcn_raw_buffer_load_b128(rx, o_aux + it * 4 * p.ldaux * 4, 0, EPI_LOAD_AUX);
     };
     // the bias is added on the read side, where a lane keeps the same 4 columns for all 16 row segments of a half: two
     // loads per lane, issued ahead of the residual requests (vmcnt retires in order)
