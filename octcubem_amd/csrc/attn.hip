@@ -273,7 +273,18 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : ATT_OCC_FWD64)) vo
   const float l_tot = ONES_SUM ? lacc[0] : (l_run + __shfl_xor(l_run, 32, 64));
   const float inv = 1.0f / l_tot;
   if (FAST) {
-    const bool bad = (qrow < N) && !(l_tot > 0.f && l_tot < 3.0e38f);      // inf, NaN or 0: overflow / whole-row underflow
+    // Give up (the safe kernel, enqueued behind this one, then recomputes everything) unless every row sum lies in [2^-100, 2^100] AND
+    // every accumulator of O is finite.  A finite row sum is not enough: O accumulates p * v before the normalisation, so a row whose
+    // largest score is ~ 2^126 (a sum just under FLT_MAX) overflows in O for |v| > 4 -- met in practice: a ViT-L decoder driven at 85 x
+    // its recipe's learning rate reached logits of 87 (natural units) after 790 steps, the row sums passed the old "finite and positive"
+    // test and O came out +inf (tools/train_sanity.py; tests: "o_overflow").  2^100 leaves 2^27 for |v| and for the number of keys;
+    // the lower bound keeps the terms within 2^-26 of the largest one normal numbers (bf16 P has fp32's exponent range).
+    bool bad = !(l_tot > 7.9e-31f && l_tot < 1.2e30f);      // also catches NaN
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) bad |= !(__builtin_fabsf(oacc[d][g]) < 3.0e38f);
+    bad = bad && (qrow < N);
     if (__any(bad) && lane == 0) atomicOr(flag, 1);
   }
   if (qrow < N) {

@@ -755,18 +755,25 @@ def test_fused_adamw_resumes_from_its_own_and_from_a_torch_adamw_state():
 
 
 @pytest.mark.parametrize("HD", [64, 32])
-@pytest.mark.parametrize("kind", ["overflow", "underflow"])
+@pytest.mark.parametrize("kind", ["overflow", "underflow", "o_overflow", "weak_underflow"])
 def test_attention_optimistic_forward_falls_back(HD, kind):
     """The optimistic forward (no running max) must hand over to the online-max kernel when a score leaves exp2's range:
-    logits of +-400 (natural units) in one row -> overflow / whole-row underflow without max subtraction."""
+    logits of +-400 (natural units) in one row -> overflow / whole-row underflow without max subtraction.  Two quieter cases:
+    "o_overflow" -- one logit of +87.3, so that the row SUM stays a finite fp32 number (2^126) but the accumulator of O, which holds
+    p * v before the normalisation, overflows for |v| = 6 (found by training ViT-L far above its recipe's learning rate: O came out
+    +inf while the row-sum test passed); "weak_underflow" -- every logit of a row at -75: the row sum is a positive 2^-100-ish number
+    whose smaller terms are no longer normal numbers."""
     B, H, N = 1, 2, 200
     g = torch.Generator().manual_seed(11)
     x = torch.randn(B * N, 3, H, HD, generator=g)
-    big = (400.0 * HD ** 0.5) ** 0.5
+    logit = {"overflow": 400.0, "underflow": 400.0, "o_overflow": 87.3, "weak_underflow": 75.0}[kind]
+    big = (logit * HD ** 0.5) ** 0.5
     x[5, 0, 1] = big / HD ** 0.5                         # query 5 of head 1 ...
-    x[:, 1, 1] = (-1.0 if kind == "underflow" else 0.0) * big / HD ** 0.5 + 0.01 * x[:, 1, 1]
-    if kind == "overflow":
-        x[77, 1, 1] = big / HD ** 0.5                    # ... meets key 77: q.k*scale = +400
+    x[:, 1, 1] = (-1.0 if "underflow" in kind else 0.0) * big / HD ** 0.5 + 0.01 * x[:, 1, 1]
+    if "overflow" in kind:
+        x[77, 1, 1] = big / HD ** 0.5                    # ... meets key 77: q.k*scale = +logit
+    if kind == "o_overflow":
+        x[77, 2, 1] = 6.0                                # ... whose value row is large enough for p * v to leave fp32
     qkv = bf(x.reshape(B * N, -1)).to(DEV)
     o, lse = ops.attn_fwd(qkv, B, N, H, HD, HD ** -0.5, optimistic=True)
     o_safe, lse_safe = ops.attn_fwd(qkv, B, N, H, HD, HD ** -0.5, optimistic=False)
