@@ -783,6 +783,81 @@ def test_attention_optimistic_forward_falls_back(HD, kind):
     assert rel(o, o_ref) < 6e-3
 
 
+@pytest.mark.parametrize("HD", [64, 32])
+@pytest.mark.parametrize("logit", [20.0, 50.0, 87.3])
+def test_attention_backward_at_peaked_logits(HD, logit):
+    """Both backward forms on rows whose softmax is a near-one-hot (logits of 20 ... 87 natural units, the regime a diverging run
+    reaches: see test_attention_optimistic_forward_falls_back): finite, and as close to the fp64 gradient as at ordinary logits
+    (measured 3e-3 ... 1.1e-2) -- the backward recomputes P from the saved LSE, P <= 1 whatever the logits."""
+    B, H, N = 1, 2, 300
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B * N, 3, H, HD, generator=g)
+    big = (logit * HD ** 0.5) ** 0.5
+    for qi in (5, 9, 100, 250):
+        x[qi, 0, 1] = big / HD ** 0.5
+    x[:, 1, 1] = 0.01 * x[:, 1, 1]
+    x[77, 1, 1] = big / HD ** 0.5
+    x[77, 2, 1] = 6.0
+    qkv = bf(x.reshape(B * N, -1)).to(DEV)
+    do = bf(torch.randn(B * N, H * HD, generator=g)).to(DEV)
+    o, lse = ops.attn_fwd(qkv, B, N, H, HD, HD ** -0.5)
+    qd = qkv.double().requires_grad_(True)
+    o_ref, _ = attn_ref(qd, B, N, H, HD)
+    o_ref.backward(do.double())
+    assert torch.isfinite(o).all() and rel(o, o_ref) < 6e-3
+    for fused in (True, False):
+        dq = ops.attn_bwd(qkv, o, do, lse, B, N, H, HD, HD ** -0.5, fused=fused)
+        assert torch.isfinite(dq).all()
+        assert rel(dq, qd.grad) < 2e-2, (fused, rel(dq, qd.grad))
+
+
+@pytest.mark.parametrize("mag", [1e-3, 1.0, 1e2, 3e3])
+def test_kernels_stay_finite_across_input_magnitudes(mag):
+    """Finite in, finite out, at operand magnitudes from 1e-3 to 3e3 (a fuzz screen for hidden range assumptions like the one the
+    optimistic attention forward had): GEMM epilogues (bias, GELU, residual, x GELU'), LayerNorm forward / backward, attention."""
+    g = torch.Generator().manual_seed(int(mag * 1000) % 9973)
+    M, K, N = 700, 512, 768
+    x = bf(torch.randn(M, K, generator=g) * mag).to(DEV)
+    w = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
+    b = (torch.randn(N, generator=g) * mag).to(DEV)
+    res = (torch.randn(M, N, generator=g) * mag).to(DEV)
+    ref = x.double() @ w.double().t() + b.double()
+    y = ops.linear_fwd(x, w, b, "bf16")
+    pre, act = ops.linear_fwd(x, w, b, "gelu")
+    yr = ops.linear_fwd(x, w, b, "resid", res=res)
+    for t_ in (y, pre, act, yr):
+        assert torch.isfinite(t_).all()
+    assert rel(y, ref) < 4e-3 and rel(act, torch.nn.functional.gelu(ref)) < 6e-3 and rel(yr, ref + res.double()) < 1e-5 + 4e-3
+    dy = bf(torch.randn(M, N, generator=g) * mag).to(DEV)
+    pre_k = bf(torch.randn(M, K, generator=g) * mag).to(DEV)
+    dx = ops.linear_dgrad(dy, w, pre=pre_k)
+    xg = pre_k.double().requires_grad_(True)
+    torch.nn.functional.gelu(xg).backward(dy.double() @ w.double())
+    assert torch.isfinite(dx).all() and rel(dx, xg.grad) < 6e-3
+    # LayerNorm: large offsets and tiny / huge spreads
+    xf = (torch.randn(M, K, generator=g) * mag + 10 * mag).to(DEV)
+    gam = (1 + 0.1 * torch.randn(K, generator=g)).to(DEV); bet = (0.1 * torch.randn(K, generator=g)).to(DEV)
+    yl, mean, rstd = ops.layernorm_fwd(xf, gam, bet, 1e-6)
+    xd = xf.double().requires_grad_(True)
+    yref = torch.nn.functional.layer_norm(xd, (K,), gam.double(), bet.double(), 1e-6)
+    assert torch.isfinite(yl).all() and rel(yl, yref) < 5e-3
+    dyl = bf(torch.randn(M, K, generator=g)).to(DEV)
+    yref.backward(dyl.double())
+    dgam = torch.zeros(K, device=DEV); dbet = torch.zeros(K, device=DEV)
+    dxl, _ = ops.layernorm_bwd(dyl, xf, mean, rstd, gam, dgam, dbet)
+    assert torch.isfinite(dxl).all() and rel(dxl, xd.grad) < 2e-3 + 2e-3 * (mag < 1e-2)     # eps matters at 1e-3: fp32 rstd rounding
+    # attention: q, k of this magnitude give logits up to ~ mag^2 * 4 sqrt(hd)
+    for HD in (32, 64):
+        Bn, H, Nn = 1, 2, 130
+        am = min(mag, 3.0)
+        qkv = bf(torch.randn(Bn * Nn, 3 * H * HD, generator=g) * am).to(DEV)
+        do = bf(torch.randn(Bn * Nn, H * HD, generator=g)).to(DEV)
+        o, lse = ops.attn_fwd(qkv, Bn, Nn, H, HD, HD ** -0.5)
+        o_ref, _ = attn_ref(qkv, Bn, Nn, H, HD)
+        dq = ops.attn_bwd(qkv, o, do, lse, Bn, Nn, H, HD, HD ** -0.5)
+        assert torch.isfinite(o).all() and torch.isfinite(dq).all() and rel(o, o_ref) < 8e-3
+
+
 @pytest.mark.parametrize("B,N,H,HD,fused", [(2, 5121, 16, 32, None), (4, 1281, 16, 64, None), (4, 1281, 16, 64, True),
                                             (2, 2049, 16, 32, False)])
 def test_attention_is_bit_reproducible_under_memory_pressure(B, N, H, HD, fused):
