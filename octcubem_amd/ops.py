@@ -634,7 +634,17 @@ import weakref
 _grad_sidecar = {}
 
 
+def _sidecar_purge():
+    # entries whose fp32 gradient is gone can never be claimed: the first Block of a stack hands its gradient to a consumer that is
+    # not a Block (sequence assembly), and its bf16 copy -- 0.34 / 0.67 GB at 128 volumes -- would otherwise stay pinned here
+    # (the allocator hands out the same addresses step after step, so in practice two to four stale entries: 1.9 of the 252 GiB
+    # a 128-volume micro-batch allocated)
+    for k in [k for k, ent in _grad_sidecar.items() if ent[0]() is None]:
+        del _grad_sidecar[k]
+
+
 def _sidecar_put(dx: torch.Tensor, dxb: torch.Tensor, colsum: torch.Tensor):
+    _sidecar_purge()
     if len(_grad_sidecar) > 64:
         _grad_sidecar.clear()
     _grad_sidecar[dx.data_ptr()] = (weakref.ref(dx), dxb, colsum)
@@ -668,6 +678,8 @@ class BlockFn(torch.autograd.Function):
         Bn, N = shp[0], shp[1]
         HD = C // H
         scale = HD ** -0.5
+        if _grad_sidecar:
+            _sidecar_purge()
         wqkv, bqkv, wproj, bproj, w1, b1, w2, b2 = lp
         g1, be1, g2, be2 = params[0], params[1], params[2], params[3]
         x2d = _chk(x.reshape(-1, C), F32, "block input")
