@@ -55,8 +55,9 @@ namespace octmae {
 // =====================================================================================================
 // FAST = optimistic variant: no running max at all (reference point 0 in the scaled log2 domain).  Floating point is
 // scale-free, so exp2(s) / sum exp2(s) is exactly as accurate as the max-subtracted form as long as nothing overflows
-// (s*scale*log2e > 127) or a whole row underflows; pre-norm ViT logits are nowhere near that.  The kernel checks every
-// row sum at the end and raises `*flag` if one is not a finite positive number; the host ALWAYS enqueues the safe
+// or underflows -- in the row sums OR in the un-normalised accumulators of O -- and the logits of a healthy pre-norm ViT are
+// nowhere near that (a diverging one's are: see the give-up test at the end of the kernel).  The kernel raises `*flag` unless every
+// row sum lies in [2^-100, 2^100] and every O accumulator is finite; the host ALWAYS enqueues the safe
 // (online-max) kernel right after, which returns immediately unless the flag is set and otherwise recomputes everything.
 // No host synchronisation, and the result is always the safe one when it matters.  What the fast variant saves is VALU
 // work, the limiter of this kernel: no max chain, no rescale, and the score accumulators start from the inline constant 0
