@@ -576,3 +576,35 @@ def test_dynamic_loss_scale_state_machine(golden_dir):
     sd = misc.NativeScalerWithGradNormCount(fp32=True)
     sd.load_state_dict(st)                                          # a bf16 / fp32 run accepts the entry and keeps scale 1
     assert sd.get_scale() == 1.0
+
+
+def test_non_finite_input_gives_non_finite_loss_and_leaves_no_state_behind(golden_dir):
+    """A NaN / Inf volume must come out as a non-finite loss (what the engines' guard looks for: engine_pretrain.py:153-161), without
+    a hang, and must not poison the next, clean step: every kernel-side flag and workspace (the optimistic attention forward's
+    give-up flag, the dQ workspace, LayerNorm partials) is re-initialised per launch, and the gradients of the bad step are zeroed
+    by zero_grad like any others."""
+    z, cfg, P = small(golden_dir)
+    m = build(cfg, P)
+    m.train()
+    imgs = torch.from_numpy(z["imgs"]).to(DEV)
+    noise = torch.from_numpy(z["noise"]).to(DEV)
+    ratio = float(z["mask_ratio"])
+    loss0, pred0, _ = m(imgs, mask_ratio=ratio, noise=noise)
+    loss0.backward()
+    g0 = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    for bad_value in (float("nan"), float("inf")):
+        bad = imgs.clone()
+        bad[0, 0, 1, 3, 5] = bad_value
+        m.zero_grad()
+        loss_b, pred_b, _ = m(bad, mask_ratio=ratio, noise=noise)
+        loss_b.backward()
+        torch.cuda.synchronize()
+        assert not bool(torch.isfinite(loss_b))
+        m.zero_grad()
+        loss1, pred1, _ = m(imgs, mask_ratio=ratio, noise=noise)
+        loss1.backward()
+        assert torch.equal(pred1, pred0) and float(loss1.detach()) == float(loss0.detach())
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                assert torch.isfinite(p.grad).all(), k
+                assert rel(p.grad, g0[k]) < 1e-5 or float(g0[k].norm()) < 1e-12, k
