@@ -207,6 +207,11 @@ def main():
                          "attn_bwd_hd64_form, attn_bwd_tail_fused, gemm_mfma16) or ops.<NAME> flags (ops.FORCE_TWO_STAGE=1, "
                          "ops.ATTN_BWD_FUSED32=0, ...); repeatable.  Isolated kernel A/Bs do not always carry over to the step "
                          "(DESIGN.md section 5, round 4), so defaults are decided here")
+    ap.add_argument("--host-inputs", type=int, default=0, choices=[0, 1, 2],
+                    help="0 (the contract: inputs resident in HBM when the timed region starts); 1: every micro-batch starts in pinned "
+                         "host memory and is copied on the compute stream, as the engines do (samples.to(device, non_blocking=True)); "
+                         "2: the same copies on a side stream, one micro-batch ahead.  For the PCIe-inclusive rate noted in DESIGN.md; "
+                         "never the headline value")
     ap.add_argument("--same-data", action="store_true",
                     help="diagnostic: every rank draws the SAME volumes (seed without the rank) -- with identical weights and masking "
                          "noise the ranks' losses must then be bit-equal (comm.last_loss_min_max_over_ranks)")
@@ -315,6 +320,26 @@ def main():
         # rank r sees different volumes (seed + rank, main_pretrain…:306)
         g = torch.Generator(device=dev).manual_seed(1234 + (0 if args.same_data else rank))
         pool_ = [torch.rand(mb, 1, 60, 256, 256, device=dev, generator=g) for _ in range(min(accum_, 2))]
+        host_ = [t.cpu().pin_memory() for t in pool_] if args.host_inputs else None
+        copy_stream = torch.cuda.Stream(device=dev) if args.host_inputs == 2 else None
+        ahead = {}
+
+        def fetch(i):
+            """micro-batch i of the step as a device tensor (--host-inputs: copied from pinned host memory inside the timed region)"""
+            if not args.host_inputs:
+                return pool_[i % len(pool_)]
+            if copy_stream is None:
+                return host_[i % len(host_)].to(dev, non_blocking=True)
+            def start(j):
+                with torch.cuda.stream(copy_stream):
+                    t = host_[j % len(host_)].to(dev, non_blocking=True)
+                    ev = torch.cuda.Event(); ev.record(copy_stream)
+                return t, ev
+            t, ev = ahead.pop(i, None) or start(i)
+            ahead[(i + 1) % accum_] = start(i + 1)           # the next micro-batch (of this or the next step) under this one's compute
+            torch.cuda.current_stream().wait_event(ev)
+            t.record_stream(torch.cuda.current_stream())
+            return t
 
         def step_(exchange=True):
             opt.zero_grad()
@@ -322,7 +347,7 @@ def main():
             for i in range(accum_):
                 if os.environ.get("OCTMAE_BENCH_FAKE_OOM") and mb == 128:     # exercises the fallback (tests only)
                     raise torch.OutOfMemoryError("simulated")
-                loss_, _, _ = model(pool_[i % len(pool_)], mask_ratio=0.75)
+                loss_, _, _ = model(fetch(i), mask_ratio=0.75)
                 last = loss_
                 scaler(loss_ / accum_, opt, parameters=params, update_grad=(exchange and i == accum_ - 1), clip_grad=args.clip_grad)
             return last
@@ -474,6 +499,9 @@ def main():
         if board_stats is not None:
             out["board"] = board_stats
         out["memory"] = memory
+        if args.host_inputs:
+            out["inputs"] = {1: "pinned host memory, copied on the compute stream inside the timed region (PCIe-inclusive)",
+                             2: "pinned host memory, copied on a side stream one micro-batch ahead (PCIe-inclusive)"}[args.host_inputs]
         if proxy is not None:
             out["per_rank_proxy"] = {"what": "one GPU running the per-rank share of an N-GPU step (256 / N volumes, one micro-batch, "
                                              "no communication): ratio_to_256 = its volumes/s over this line's value",

@@ -28,7 +28,7 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
     optimizer.zero_grad()
     n_iter = len(data_loader)
     float_targets = isinstance(criterion, torch.nn.BCEWithLogitsLoss) or getattr(args, "task_mode", "") == "regression"
-    for data_iter_step, (samples, targets) in enumerate(metric_logger.log_every(data_loader, print_freq, header)):
+    for data_iter_step, (samples, targets) in enumerate(metric_logger.log_every(misc.prefetched(data_loader, device, args, only=(0, 1)), print_freq, header)):
         if data_iter_step % accum_iter == 0:
             lr_sched.adjust_learning_rate(optimizer, data_iter_step / n_iter + epoch, args)
         samples = samples.to(device, non_blocking=True)

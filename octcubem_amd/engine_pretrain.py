@@ -29,7 +29,7 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
     accum_iter = args.accum_iter
     optimizer.zero_grad()
     n_iter = len(data_loader)
-    for data_iter_step, batch in enumerate(metric_logger.log_every(data_loader, print_freq, header)):
+    for data_iter_step, batch in enumerate(metric_logger.log_every(misc.prefetched(data_loader, device, args), print_freq, header)):
         samples = batch[0] if isinstance(batch, (tuple, list)) else batch
         if data_iter_step % accum_iter == 0:
             lr_sched.adjust_learning_rate(optimizer, data_iter_step / n_iter + epoch, args)
@@ -124,7 +124,7 @@ def train_one_epoch_joint(model: torch.nn.Module, data_loader: Iterable, optimiz
     optimizer.zero_grad()
     n_iter = len(data_loader)
     secondary_iter = iter(data_loader_2d)
-    for data_iter_step, (samples, data_info) in enumerate(metric_logger.log_every(data_loader, print_freq, header)):
+    for data_iter_step, (samples, data_info) in enumerate(metric_logger.log_every(misc.prefetched(data_loader, device, args), print_freq, header)):
         if data_iter_step % accum_iter == 0:
             lr_sched.adjust_learning_rate(optimizer, data_iter_step / n_iter + epoch, args)
         data_dict = data_info[1]

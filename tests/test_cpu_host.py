@@ -290,3 +290,14 @@ def test_bench_board_sampler_reads_power_and_clock(tmp_path, monkeypatch):
     st = b.stop()
     assert st is not None and st["samples"] >= 2
     assert abs(st["power_w_avg"] - 1350.0) < 1e-6 and abs(st["sclk_mhz_avg"] - 1950.0) < 1e-6 and st["power_cap_w"] == 1400.0
+
+
+def test_device_prefetcher_is_a_pass_through_on_the_cpu():
+    from octcubem_amd import misc
+    batches = [(torch.full((2, 3), float(i)), {"id": i, "t": torch.tensor([i])}) for i in range(5)]
+    assert misc.prefetched(batches, "cpu") is batches                      # no GPU: the loader itself
+    pf = misc.DevicePrefetcher(batches, "cpu", only=(0,))
+    assert len(pf) == 5
+    out = list(pf)
+    assert all(a is b for a, b in zip(out, batches))
+    assert list(misc.DevicePrefetcher([], "cpu")) == []

@@ -608,3 +608,30 @@ def test_non_finite_input_gives_non_finite_loss_and_leaves_no_state_behind(golde
             if p.grad is not None:
                 assert torch.isfinite(p.grad).all(), k
                 assert rel(p.grad, g0[k]) < 1e-5 or float(g0[k].norm()) < 1e-12, k
+
+
+def test_device_prefetcher_moves_one_batch_ahead_and_keeps_order():
+    """misc.DevicePrefetcher (the engines' input pipeline): same batches, same order, tensors on the device -- all of them, or only
+    the listed positions -- also for nested containers, a one-batch loader, an early break, and a second pass over the same loader."""
+    from octcubem_amd import misc
+    g = torch.Generator().manual_seed(0)
+    batches = [(torch.rand(3, 1, 6, 32, 32, generator=g).pin_memory(), [torch.tensor([i]), {"name": f"p{i}", "w": torch.rand(2, generator=g)}]) for i in range(7)]
+    for only in (None, (0,)):
+        pf = misc.prefetched(batches, torch.device(DEV), args=None, only=only)
+        assert isinstance(pf, misc.DevicePrefetcher) and len(pf) == 7
+        for rep in range(2):
+            seen = 0
+            for i, (x, info) in enumerate(pf):
+                assert x.is_cuda and torch.equal(x.cpu(), batches[i][0])
+                y = (x * 2).sum()                                            # use it on the compute stream
+                assert info[1]["name"] == f"p{i}"
+                assert info[0].is_cuda == (only is None) and info[1]["w"].is_cuda == (only is None)
+                assert torch.equal(info[1]["w"].cpu(), batches[i][1][1]["w"])
+                seen += 1
+                if rep == 1 and i == 3:
+                    break
+            assert seen == (7 if rep == 0 else 4)
+            assert torch.isfinite(y)
+    assert [t.item() for t in misc.DevicePrefetcher([torch.tensor(5.0)], DEV)] == [5.0]
+    class A: prefetch_to_device = False
+    assert misc.prefetched(batches, torch.device(DEV), args=A()) is batches
