@@ -70,7 +70,7 @@ def evaluate(data_loader: Iterable, model: torch.nn.Module, device: torch.device
     criterion = criterion or torch.nn.CrossEntropyLoss()
     model.eval()
     logits_all, targets_all, loss_sum, n = [], [], 0.0, 0
-    for samples, targets in data_loader:
+    for samples, targets in misc.prefetched(data_loader, device, None, only=(0, 1)):
         samples = samples.to(device, non_blocking=True)
         targets = targets.to(device, non_blocking=True)
         out = model(samples).float()
