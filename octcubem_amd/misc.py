@@ -355,7 +355,8 @@ class DevicePrefetcher:
         if torch.is_tensor(obj):
             return obj.to(self.device, non_blocking=True)
         if isinstance(obj, tuple):
-            return tuple(self._move(o) for o in obj)
+            items = [self._move(o) for o in obj]
+            return type(obj)(*items) if hasattr(obj, "_fields") else tuple(items)        # namedtuples keep their type
         if isinstance(obj, list):
             return [self._move(o) for o in obj]
         if isinstance(obj, dict):
@@ -382,7 +383,8 @@ class DevicePrefetcher:
         def start(batch):
             with torch.cuda.stream(side):
                 if self.only is not None and isinstance(batch, (tuple, list)):
-                    moved = type(batch)(self._move(o) if i in self.only else o for i, o in enumerate(batch))
+                    items = [self._move(o) if i in self.only else o for i, o in enumerate(batch)]
+                    moved = type(batch)(*items) if hasattr(batch, "_fields") else (tuple(items) if isinstance(batch, tuple) else items)
                 else:
                     moved = self._move(batch)
                 ev = torch.cuda.Event()
