@@ -108,9 +108,15 @@ def load():
     return lib
 
 
+_FN = {}
+
+
 def call(name, *args):
     """Invoke a C-ABI entry point and turn its status code into an exception."""
-    rc = getattr(load(), name)(*args)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(load(), name)
+    rc = fn(*args)
     if rc != 0:
         kind = ("bad argument" if rc == -1 else "unsupported combination" if rc == -2 else "librccl not found" if rc == -3
                 else f"ncclResult_t {rc - 10000}" if rc >= 10000 else f"hipError_t {rc}")

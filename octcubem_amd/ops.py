@@ -26,7 +26,12 @@ EPI_BF16, EPI_F32, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM = range(6)
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    # the raw handle of the current stream of the current device: 0.3 us, against 8 us for torch.cuda.current_stream().cuda_stream
+    # (a Stream object per call) -- per launch, ~240 times per forward + backward (tools/host_overhead_profile.py)
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    except AttributeError:      # a PyTorch without these private accessors
+        return torch.cuda.current_stream().cuda_stream
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -406,6 +411,30 @@ def set_option(key: str, value: int) -> int:
     return prev
 
 
+_N_CU = {}
+# fused backward only if its B * H workgroups fill this share of their rounds of CUs (0: always; OCTMAE_ATTN_BWD_MIN_FILL for A/B runs)
+ATTN_BWD_FUSED_MIN_FILL = float(os.environ.get("OCTMAE_ATTN_BWD_MIN_FILL", "0.74"))
+
+
+def attn_bwd_use_fused(B: int, H: int, HD: int, device=None) -> bool:
+    """Which backward a call takes when the caller does not say.  The fused single-pass kernels run ONE workgroup per (batch, head) and CU:
+    B * H workgroups, in rounds of the CU count.  Below three quarters of a round -- or of the last of a few rounds -- the idle CUs cost more
+    than the dQ + dK/dV pair's two extra matrix products (it parallelises over query and key tiles as well): measured through the whole
+    step on MI355X (H = 16; profiles/r04_small_batch.txt), 1 volume 42.2 vs 23.6 volumes/s for the pair, 2: 67.8 vs 43.0, 4: 98.9 vs 74.1,
+    8: 126.6 vs 114.8, 12 (192 workgroups): equal, 16 (one full round): 148.3 vs 139.6 for the fused form, 24 (1.5 rounds): equal."""
+    if not ATTN_BWD_FUSED[HD]:
+        return False
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    ncu = _N_CU.get(idx)
+    if ncu is None:
+        ncu = _N_CU[idx] = int(torch.cuda.get_device_properties(idx).multi_processor_count)
+    wgs = B * H
+    rounds = -(-wgs // ncu)
+    return wgs >= ATTN_BWD_FUSED_MIN_FILL * rounds * ncu
+
+
 def attn_bwd(qkv, o, dout, lse, B, N, H, HD, scale, fused: Optional[bool] = None, delta: Optional[torch.Tensor] = None):
     """Gradient of attn_fwd w.r.t. the packed qkv.  Algorithmic work ("x3" in total): 4 matrix products =
     8 B H N^2 HD flop (dP, dV, dK, dQ); the recomputation of S is not counted.  ``delta`` (fp32 [B * N, H], from
@@ -413,7 +442,7 @@ def attn_bwd(qkv, o, dout, lse, B, N, H, HD, scale, fused: Optional[bool] = None
     dqkv = torch.empty_like(qkv)
     st = _stream()
     unit = 2.0 * B * H * N * N * HD
-    if ATTN_BWD_FUSED[HD] if fused is None else fused:
+    if attn_bwd_use_fused(B, H, HD, qkv.device) if fused is None else fused:
         kib = load().octmae_attn_bwd_fused_ws_kib(B, N, H, HD)
         if kib < 0:
             raise RuntimeError("octmae_attn_bwd_fused_ws_kib: unsupported shape")
@@ -579,9 +608,9 @@ class AttentionFn(torch.autograd.Function):
         if gbproj is not None:
             colsum_accum(d2 if d2.dtype in (F32, BF16) else dob, gbproj)
         linear_wgrad_accum(dob, o, gwproj)
-        fused_bwd = ATTN_BWD_FUSED[HD]
+        fused_bwd = attn_bwd_use_fused(Bn, H, HD, qkv.device)
         do, delta = linear_dgrad_delta(dob, wproj_lp, o, H, HD) if fused_bwd else (linear_dgrad(dob, wproj_lp), None)
-        dqkv = attn_bwd(qkv, o, do, lse, Bn, N, H, HD, scale, delta=delta)
+        dqkv = attn_bwd(qkv, o, do, lse, Bn, N, H, HD, scale, fused=fused_bwd, delta=delta)
         linear_wgrad_accum(dqkv, y2, gwqkv, gbqkv)
         notify_grad_ready(ctx.params)
         dy = linear_dgrad(dqkv, wqkv_lp).view(ctx.shp)
@@ -743,9 +772,9 @@ class BlockFn(torch.autograd.Function):
             if gbproj is not None:
                 colsum_accum(dx2b, gbproj)
         # ---- attention
-        fused_bwd = ATTN_BWD_FUSED[HD]
+        fused_bwd = attn_bwd_use_fused(Bn, H, HD, qkv.device)
         do, delta = linear_dgrad_delta(dx2b, wproj, o, H, HD) if fused_bwd else (linear_dgrad(dx2b, wproj), None)
-        dqkv = attn_bwd(qkv, o, do, lse, Bn, N, H, HD, scale, delta=delta)
+        dqkv = attn_bwd(qkv, o, do, lse, Bn, N, H, HD, scale, fused=fused_bwd, delta=delta)
         # the qkv bias gradient rides in the weight-gradient GEMM (column sums of its dY operand); fusing it into the attention
         # backward kernels had been measured and dropped (+10..25 % on their main loops for a 2 % pass)
         linear_wgrad_accum_pair((dx2b, o, gwproj, None), (dqkv, y1, gwqkv, gbqkv))

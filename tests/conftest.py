@@ -12,11 +12,29 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "small_batch_rule: runs with ops.attn_bwd_use_fused's fill rule active (see conftest.py)")
 
 
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _fused_attention_backward_at_test_sizes(request):
+    """The GPU tests run models of 2-3 samples and 2-3 heads.  ops.attn_bwd_use_fused would hand such a backward to the dQ + dK/dV pair
+    (B * H workgroups do not fill the chip) and the production kernels of the benchmark -- the fused single-pass backward with the
+    delta from the proj dgrad's epilogue -- would never run inside a model test: the fill rule is switched off for the tests (the
+    fused form wherever ATTN_BWD_FUSED says so, as before the rule existed) except in those that mark themselves
+    ``small_batch_rule`` and test the rule itself."""
+    if "gpu" not in request.keywords or "small_batch_rule" in request.keywords:
+        yield
+        return
+    from octcubem_amd import ops
+    old = ops.ATTN_BWD_FUSED_MIN_FILL
+    ops.ATTN_BWD_FUSED_MIN_FILL = 0.0
+    yield
+    ops.ATTN_BWD_FUSED_MIN_FILL = old
 
 
 # ---- measured-error ledger: parity(label, value, bound) asserts value <= bound AND records the measurement; at session end the

@@ -19,7 +19,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
-    from octcubem_amd import models_mae, misc, optim as foptim, lr_sched, engine_pretrain
+    from octcubem_amd import models_mae, misc, ops, optim as foptim, lr_sched, engine_pretrain
 from oracle import mae3d_ref as O
 from tests.conftest import parity
 
@@ -635,3 +635,31 @@ def test_device_prefetcher_moves_one_batch_ahead_and_keeps_order():
     assert [t.item() for t in misc.DevicePrefetcher([torch.tensor(5.0)], DEV)] == [5.0]
     class A: prefetch_to_device = False
     assert misc.prefetched(batches, torch.device(DEV), args=A()) is batches
+
+
+@pytest.mark.small_batch_rule
+def test_small_batches_take_the_two_kernel_attention_backward(golden_dir, monkeypatch):
+    """ops.attn_bwd_use_fused: one workgroup per (batch, head) cannot fill 256 CUs at a few samples, so such a backward goes to the
+    dQ + dK/dV pair (the whole step at 1 volume: 42 vs 24 volumes/s).  The rule itself, and the model's gradients under it against the
+    reference golden -- the same bounds as the fused path's test."""
+    assert ops.ATTN_BWD_FUSED_MIN_FILL > 0.5
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    for B, H, want in ((1, 16, False), (8, 16, False), (11, 16, False), (12, 16, ncu <= 256), (16, 16, ncu <= 256), (20, 16, False),
+                       (24, 16, ncu == 256), (32, 16, True), (128, 16, True)):
+        if ncu == 256:
+            assert ops.attn_bwd_use_fused(B, H, 32) == want, (B, H)
+    calls = []
+    real = ops.attn_bwd
+    monkeypatch.setattr(ops, "attn_bwd", lambda *a, **k: (calls.append(k.get("fused")), real(*a, **k))[1])
+    z, cfg, P = small(golden_dir)
+    m = build(cfg, P)
+    m.train()
+    loss, pred, mask = m(torch.from_numpy(z["imgs"]).to(DEV), mask_ratio=float(z["mask_ratio"]), noise=torch.from_numpy(z["noise"]).to(DEV))
+    loss.backward()
+    assert calls and all(c is False for c in calls)                       # every Block took the pair
+    assert abs(float(loss.detach()) - float(z["loss"])) <= 1e-3 * abs(float(z["loss"]))
+    total = float(np.sqrt(sum(float(z[f"gnorm/{k}"]) ** 2 for k, _ in m.named_parameters())))
+    for k, p in m.named_parameters():
+        gn = float(z[f"gnorm/{k}"])
+        if gn >= 1e-3 * total:
+            assert abs(float(p.grad.double().norm()) - gn) <= 1.5e-2 * gn, k
