@@ -23,9 +23,18 @@ extern "C" {
 /* The ONE place the ABI number lives: octmae_abi_version() returns it (csrc/probe.hip), octcubem_amd/_lib.py parses it
  * from this header and refuses a library that reports another number, __graft_entry__.build() and the tests compare the two.
  * 4: octmae_attn_bwd_dq_rowconst.  5: octmae_comm_* (RCCL), octmae_attn_bwd_fused + workspace query.  7: octmae_set_option, octmae_scatter_add_rows, octmae_dec_assemble_bwd.
- * 8: octmae_linear_dgrad_delta, octmae_attn_bwd_fused_delta.  9: octmae_wgrad_accum_pair, octmae_wgrad_split_plan. */
-#define OCTMAE_ABI_VERSION 9
+ * 8: octmae_linear_dgrad_delta, octmae_attn_bwd_fused_delta.  9: octmae_wgrad_accum_pair, octmae_wgrad_split_plan.
+ * 10: octmae_lp_dtype. */
+#define OCTMAE_ABI_VERSION 10
 int octmae_abi_version(void);
+
+/* The 16-bit operand type this library was built for: 0 = bfloat16 (liboctmae.so, the shipped build; BASELINE's headline type),
+ * 1 = IEEE half (`make -C octcubem_amd/csrc F16=1` -> liboctmae_f16.so: the same kernels with the type, the conversions and the
+ * MFMA opcodes switched in csrc/common.hpp).  The reference's own default arithmetic is fp16 autocast + GradScaler
+ * (Pre-training/main_pretrain_oph_joint_2d512_flash_attn.py:259-263, custom_util/misc.py:311-312); the half build is how the
+ * north star's 1e-3 on pred / gradients is shown directly (tests/test_gpu_f16_parity.py).  Every "bf16" buffer of this header is
+ * a buffer of THIS type; the host side allocates with the matching torch dtype (octcubem_amd/ops.py: BF16). */
+int octmae_lp_dtype(void);
 
 /* Kernel-selection switches for same-process A/B measurements and for tests that cover both forms of a kernel (no reference
  * counterpart: the reference's kernels come from its libraries).  Returns the previous value, -1 for an unknown key.

@@ -16,6 +16,7 @@ _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 # name -> argtypes ; every function returns int (0 ok, <0 bad argument, >0 hipError_t)
 SIGNATURES = {
     "octmae_abi_version": [],
+    "octmae_lp_dtype": [],
     "octmae_set_option": [C.c_char_p, _i],
     "octmae_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "octmae_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],

@@ -64,7 +64,7 @@ class ParamArena:
         self.total = (off + ALIGN - 1) // ALIGN * ALIGN
         self.device = dev
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
-        self.lp = torch.zeros(self.total, dtype=torch.bfloat16, device=dev)
+        self.lp = torch.zeros(self.total, dtype=ops.BF16, device=dev)
         self.grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.offset: Dict[int, int] = {}
         with torch.no_grad():

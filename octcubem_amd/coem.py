@@ -17,6 +17,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
+from ._autocast import autocast_invariant
 
 
 def _native_comm(x: torch.Tensor):
@@ -86,6 +87,7 @@ def gather_features(image_features, enface_features, local_loss=False, gather_wi
     return torch.cat(gi, dim=0), torch.cat(ge, dim=0)
 
 
+@autocast_invariant
 class ClipLoss(nn.Module):
     def __init__(self, local_loss=False, gather_with_grad=False, cache_labels=False, rank=0, world_size=1, use_horovod=False,
                  correct_label=0):
@@ -156,6 +158,7 @@ def gather_features_3mod(image_features, enface1_features, enface2_features, t_w
     return tuple(out)
 
 
+@autocast_invariant
 class ThreeModalityClipLoss(nn.Module):
     """open_clip/loss.py:230-385: symmetric InfoNCE over the three pairs (OCT, en-face 1), (OCT, en-face 2), (en-face 1,
     en-face 2) with one temperature per pair; a sample whose modality is missing carries weight 0 in that modality's terms
@@ -225,6 +228,7 @@ class ThreeModalityClipLoss(nn.Module):
         return sum(terms) / 6
 
 
+@autocast_invariant
 class CustomTextCLIP(nn.Module):
     """Two towers + a learned temperature.  ``visual`` / ``text`` are modules mapping their input to ``[B, embed_dim]`` (here:
     models_vit_st / models_vit with ``num_classes = embed_dim``); the reference builds them from config objects

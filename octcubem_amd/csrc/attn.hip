@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, (HD == 32 ? ATT_OCC_FWD32 : ATT_OCC_FWD64)) vo
     if (qrow < N) v = *reinterpret_cast<const u32x4*>(qb + (size_t)qrow * rs + 16 * s + 8 * h);
     qf[s] = scale_frag(v, sc2);
   }
-  const u32x4 ones_w = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  const u32x4 ones_w = {OCTMAE_LP_ONE_PAIR, OCTMAE_LP_ONE_PAIR, OCTMAE_LP_ONE_PAIR, OCTMAE_LP_ONE_PAIR};
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_w);
 
   f32x16 oacc[DB], lacc;

@@ -33,7 +33,7 @@ namespace octmae {
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 __device__ __forceinline__ f32x4_t mfma16(bf16x8 a, bf16x8 b, f32x4_t c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  return mfma16x16(a, b, c);
 }
 
 #ifndef BWD_DMA_MID

@@ -6,7 +6,7 @@ namespace octmae {
 namespace bwd1w_util {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return mfma16x16(a, b, c); }
 
 template <int CNT>
 __device__ __forceinline__ void wait_vm() {
@@ -57,7 +57,7 @@ __device__ __forceinline__ int img_off(int row, int c8) { return row * 64 + ((c8
 // (the compiler pads nothing inside asm): the A / B operands are written by v_cvt_pk at least two instructions earlier (the
 // generator pins their last producer), the accumulate chain needs no wait states, and the read-out after the loop sits behind
 // explicit s_nops.
-#define MFMA_ACC(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+#define MFMA_ACC(acc, a, b) asm volatile(OCTMAE_MFMA32_ASM " %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
 // The lane id, computed where it is asked for (volatile: not merged with other copies, not hoisted): code behind the tile loop
 // that needs per-lane addresses derives them from this instead of keeping them -- or the lane id -- in registers across the loop.
 __device__ __forceinline__ int lane_id_fresh() {

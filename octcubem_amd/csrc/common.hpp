@@ -15,7 +15,33 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
-// ---- bf16 <-> f32 ---------------------------------------------------------------------------
+// ---- 16-bit operand type <-> f32 -------------------------------------------------------------
+// The 16-bit MFMA operand type is bfloat16 (the shipped library).  `make F16=1` (-DOCTMAE_F16) builds the SAME kernels on IEEE half:
+// every conversion and every MFMA of the library goes through the helpers below (and MFMA_ACC of attn_bwd1w.hpp), so the switch
+// is this block.  That build is the verification build of DESIGN.md section 2 (the reference's own default arithmetic is fp16 +
+// GradScaler, main_pretrain_oph_joint_2d512_flash_attn.py:259-263): 3 more mantissa bits, same kernels, same rounding points.
+// The names keep "bf" in both builds: bf16_t = the raw bits of the 16-bit operand type.
+#ifdef OCTMAE_F16
+#define OCTMAE_LP_IS_F16 1
+#define OCTMAE_LP_ONE_PAIR 0x3c003c00u       // two 1.0 of the operand type in one dword
+typedef __attribute__((ext_vector_type(8))) _Float16 lp8_t;
+__device__ __forceinline__ bf16_t f2bf(float x) {
+  _Float16 h = (_Float16)x;
+  return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  f2 v = {lo, hi};
+  h2 r = __builtin_convertvector(v, h2);      // round-to-nearest-even (v_cvt_pk_f16_f32 / two v_cvt_f16_f32), never the rtz pack
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ float bflo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
+__device__ __forceinline__ float bfhi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+#else
+#define OCTMAE_LP_IS_F16 0
+#define OCTMAE_LP_ONE_PAIR 0x3f803f80u
 // Plain casts: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN).
 __device__ __forceinline__ bf16_t f2bf(float x) {
   __bf16 h = (__bf16)x;
@@ -33,6 +59,7 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 }
 __device__ __forceinline__ float bflo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+#endif
 
 // ---- wave reductions (64 lanes) -------------------------------------------------------------
 // Wave-wide reductions on DPP (every lane of the wave must be active: all call sites sit in wave-uniform control flow).  hipcc lowers
@@ -195,9 +222,25 @@ __device__ __forceinline__ f32x2 dgelu_f2(f32x2 x) { return dgelu_exact_f2(x); }
 // D(32x32) += A(32x16) * B(16x32).  lane l: r = l & 31, h = l >> 5.
 //   A fragment element j = A[row r][k = 8h + j]      B fragment element j = B[k = 8h + j][col r]
 //   D register g      = D[row (g&3) + 8*(g>>2) + 4h][col r]
+#ifdef OCTMAE_F16
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(lp8_t, a), __builtin_bit_cast(lp8_t, b), c, 0, 0, 0);
+}
+// D(16x16) += A(16x32) * B(32x16)
+__device__ __forceinline__ f32x4 mfma16x16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(lp8_t, a), __builtin_bit_cast(lp8_t, b), c, 0, 0, 0);
+}
+#define OCTMAE_MFMA32_ASM "v_mfma_f32_32x32x16_f16"
+#else
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// D(16x16) += A(16x32) * B(32x16)
+__device__ __forceinline__ f32x4 mfma16x16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+#define OCTMAE_MFMA32_ASM "v_mfma_f32_32x32x16_bf16"
+#endif
 
 // ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3
 // of a 4x16 block of 16-bit elements; lane i of the group receives column i (rows 0..3).

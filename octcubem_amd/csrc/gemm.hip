@@ -818,7 +818,7 @@ __device__ __forceinline__ void gemm256p_body(const GemmParams& p, const int t, 
     // of its 32-row blocks each (block wb: phase 1 for wb < 2, phase 3 otherwise).  +12.5 % MFMAs in 1 / tiles_b of the tiles,
     // against a separate pass over dY (0.25 ms per qkv weight gradient at micro-batch 128).
     const bool cs_on = (EPI == EPI_ACCUM) && p.C2 != nullptr && tb == 0;
-    const u32x4 ones_w = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    const u32x4 ones_w = {OCTMAE_LP_ONE_PAIR, OCTMAE_LP_ONE_PAIR, OCTMAE_LP_ONE_PAIR, OCTMAE_LP_ONE_PAIR};
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_w);
     f32x16 csum;
 #pragma unroll
@@ -987,7 +987,7 @@ __device__ __forceinline__ bf16x8 read_fragQ(const char* lds, int rb, int s2, in
   }
 }
 
-__device__ __forceinline__ f32x4 mfma16q(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16q(bf16x8 a, bf16x8 b, f32x4 c) { return mfma16x16(a, b, c); }
 
 template <bool A_KS, bool B_KS, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm256q_kernel(const GemmParams p) {

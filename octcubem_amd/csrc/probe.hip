@@ -31,6 +31,7 @@ __global__ void probe_trread_kernel(const bf16_t* tile, bf16_t* out) {
 using namespace octmae;
 
 extern "C" int octmae_abi_version(void) { return OCTMAE_ABI_VERSION; }   // the number lives in include/octmae.h
+extern "C" int octmae_lp_dtype(void) { return OCTMAE_LP_IS_F16; }
 
 extern "C" int octmae_probe_mfma32(const void* a, const void* b, float* d, void* stream) {
   OCTMAE_CHECK_ARG(a && b && d);

@@ -4,8 +4,10 @@
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+from ._autocast import autocast_invariant
 
 
+@autocast_invariant
 class LabelSmoothingCrossEntropy(nn.Module):
     """NLL loss with label smoothing: mean_i[(1 - s) * nll_i + s * mean_c(-log p_ic)]."""
 
@@ -22,6 +24,7 @@ class LabelSmoothingCrossEntropy(nn.Module):
         return (self.confidence * nll_loss + self.smoothing * smooth_loss).mean()
 
 
+@autocast_invariant
 class SoftTargetCrossEntropy(nn.Module):
     """Cross entropy against a probability vector (what mixup / cutmix produce)."""
 

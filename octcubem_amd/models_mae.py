@@ -22,8 +22,10 @@ import torch.nn.functional as F
 from . import ops, video_vit
 from .arena import get_arena
 from .video_vit import layer_norm
+from ._autocast import autocast_invariant
 
 
+@autocast_invariant
 class MaskedAutoencoderViT(nn.Module):
     """Masked Autoencoder with VisionTransformer backbone"""
 

@@ -14,6 +14,7 @@ from . import ops
 from .arena import get_arena
 from . import video_vit
 from .video_vit import TimmBlock as Block, TimmPatchEmbed as PatchEmbed, layer_norm
+from ._autocast import autocast_invariant
 
 
 def get_2d_sincos_pos_embed(embed_dim, grid_size, cls_token=False):
@@ -30,6 +31,7 @@ def get_2d_sincos_pos_embed(embed_dim, grid_size, cls_token=False):
     return emb
 
 
+@autocast_invariant
 class MaskedAutoencoderViT(nn.Module):
     """Masked Autoencoder with VisionTransformer backbone"""
 

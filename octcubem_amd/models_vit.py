@@ -13,12 +13,14 @@ import torch.nn as nn
 from . import ops
 from .arena import get_arena
 from .video_vit import TimmBlock as Block, TimmPatchEmbed as PatchEmbed, layer_norm
+from ._autocast import autocast_invariant
 
 
 def trunc_normal_(t, std=0.02):
     return nn.init.trunc_normal_(t, std=std, a=-2 * std, b=2 * std)
 
 
+@autocast_invariant
 class VisionTransformer(nn.Module):
     """Vision Transformer with support for global average pooling"""
 

@@ -12,8 +12,10 @@ import torch.nn as nn
 from . import ops, video_vit
 from .arena import get_arena
 from .video_vit import Attention, Block, PatchEmbed
+from ._autocast import autocast_invariant
 
 
+@autocast_invariant
 class VisionTransformer(nn.Module):
     """Vision Transformer with support for global average pooling"""
 

@@ -16,9 +16,20 @@ from typing import Callable, List, Optional, Sequence
 
 import torch
 
-from ._lib import call, load
+from ._lib import OctmaeError, call, load
 
-BF16 = torch.bfloat16
+
+def _lp_dtype():
+    """The torch dtype of the library's 16-bit operand type (octmae_lp_dtype): bfloat16 for liboctmae.so, float16 for the
+    verification build liboctmae_f16.so (OCTMAE_LIB).  A missing library is reported by the first compute call, not here."""
+    try:
+        return torch.float16 if load().octmae_lp_dtype() == 1 else torch.bfloat16
+    except OctmaeError:
+        return torch.bfloat16
+
+
+BF16 = _lp_dtype()                 # named for the shipped build; every "bf16" below means "the library's 16-bit operand type"
+LP_IS_F16 = BF16 == torch.float16
 F32 = torch.float32
 _CHECK_IDS = os.environ.get("OCTMAE_CHECK_IDS", "0") == "1"    # verify the permutation contract of the assembly ops per call
 
@@ -380,7 +391,10 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None, want_bf16=
     return dx, dxb
 
 
-ATTN_OPTIMISTIC = True    # optimistic (no running max) forward first, safe kernel as the device-side fallback
+# optimistic (no running max) forward first, safe kernel as the device-side fallback.  Not in the half build: the un-normalised
+# P = exp2(s) of that kernel is an MFMA operand, and half ends at 65 504 = e^11.09 where bfloat16 has fp32's range (the online-max
+# kernel keeps P <= 2^8)
+ATTN_OPTIMISTIC = not LP_IS_F16
 
 
 def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, HD: int, scale: float, optimistic: Optional[bool] = None):

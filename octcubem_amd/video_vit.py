@@ -12,12 +12,14 @@ import torch.nn as nn
 
 from . import ops
 from .arena import get_arena
+from ._autocast import autocast_invariant
 
 
 def to_2tuple(x):
     return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
 
 
+@autocast_invariant
 class DropPath(nn.Module):
     """Stochastic depth per sample (timm DropPath): identity when drop_prob == 0 or in eval mode."""
 
@@ -36,6 +38,7 @@ class DropPath(nn.Module):
         return x * self.sample(x.shape[0], x.device).to(x.dtype).view((x.shape[0],) + (1,) * (x.ndim - 1))
 
 
+@autocast_invariant
 class PatchEmbed(nn.Module):
     """Image to Patch Embedding -- Conv3d(k = s = (t_patch, p, p)) evaluated as gather + MFMA GEMM."""
 
@@ -86,6 +89,7 @@ class PatchEmbed(nn.Module):
         return tok.view(B, T // self.t_patch_size, self.input_size[1] * self.input_size[2], -1)   # [N, T, H*W, C]
 
 
+@autocast_invariant
 class Attention(nn.Module):
     def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0, input_size=(4, 14, 14)):
         super().__init__()
@@ -138,6 +142,7 @@ class Attention(nn.Module):
         return ops.AttentionFn.apply(x, residual, wqkv, bqkv, wproj, bproj, grads, self.num_heads, *params)
 
 
+@autocast_invariant
 class TimmAttention(nn.Module):
     """timm 0.3.2 ``vision_transformer.Attention`` (one fused ``qkv`` Linear) -- the block the reference's 2-D models build
     from ``timm.models.vision_transformer.Block`` (OCTCube/models_mae.py:18,40-42).  Same kernels as ``Attention``."""
@@ -178,6 +183,7 @@ class TimmAttention(nn.Module):
         return ops.AttentionFn.apply(x, residual, wqkv, bqkv, wproj, bproj, grads, self.num_heads, *params)
 
 
+@autocast_invariant
 class TimmPatchEmbed(nn.Module):
     """timm 0.3.2 ``PatchEmbed``: Conv2d(k = s = patch) + flatten(2).transpose(1, 2), as gather + MFMA GEMM."""
 
@@ -212,6 +218,7 @@ class TimmPatchEmbed(nn.Module):
         return self.embed_tokens(x).view(x.shape[0], self.num_patches, -1)
 
 
+@autocast_invariant
 class Mlp(nn.Module):
     """timm.models.vision_transformer.Mlp: fc1 -> act -> drop -> fc2 -> drop (act = exact-erf GELU)."""
 
@@ -249,6 +256,7 @@ def layer_norm(norm: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
     return ops.LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps)
 
 
+@autocast_invariant
 class Block(nn.Module):
     """Transformer Block with specified Attention function (pre-norm residual, video_vit.py:181-184).
     The residual stream is fp32; both residual adds are fused into GEMM epilogues."""
@@ -309,6 +317,7 @@ class Block(nn.Module):
         return x
 
 
+@autocast_invariant
 class TimmBlock(Block):
     """timm 0.3.2 ``vision_transformer.Block`` signature (OCTCube/models_mae.py:40-42,54-56): fused-qkv attention."""
 
@@ -318,6 +327,7 @@ class TimmBlock(Block):
                          drop_path=drop_path, act_layer=act_layer, norm_layer=norm_layer, attn_func=TimmAttention)
 
 
+@autocast_invariant
 class FlashMixer(nn.Module):
     """Parameter layout of flash-attn's ``MHA`` (``Wqkv`` [3D, D] + ``out_proj``): what the reference's flash models hold
     under ``blocks.i.mixer`` (remap rules at models_mae_joint_res_flash_attn.py:693-724)."""
@@ -352,6 +362,7 @@ class FlashMixer(nn.Module):
         return ops.AttentionFn.apply(x, residual, wqkv, bqkv, wproj, bproj, grads, self.num_heads, *params)
 
 
+@autocast_invariant
 class FlashBlock(Block):
     """The module ``flash_attn.models.vit.create_block`` returns, as the reference uses it: pre-norm, residual carried
     separately, ``forward(hidden_states, residual=None) -> (hidden_states, residual)`` with (flash-attn 2.5.2

@@ -1,0 +1,297 @@
+"""Measures the model-level parity ledger of ONE build of the library -- the one OCTMAE_LIB selects -- against the golden vectors
+produced by the real reference and writes it to --out as JSON.  tests/test_gpu_f16_parity.py runs it twice (liboctmae.so: bfloat16
+operands; liboctmae_f16.so: IEEE-half operands, the reference's own default arithmetic) and compares the two ledgers.
+
+Why a separate process per build: the shared library is loaded once per process (octcubem_amd/_lib.py).
+
+Half needs loss scaling for its gradients (the decoder's dpred is ~1e-6 per element, below half's normal range of 6.1e-5): the loss is
+multiplied by the reference's default GradScaler scale, 65536 (torch.cuda.amp.GradScaler(); custom_util/misc.py:311-312), halved
+until the gradients are finite -- what NativeScalerWithGradNormCount(dynamic_loss_scale=True) does step by step -- and the gradients
+are divided by it before they are compared.  The bfloat16 build runs with scale 1.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from octcubem_amd import ops  # noqa: E402
+
+DEV = "cuda"
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().flatten().cpu(); b = torch.as_tensor(b).detach().double().flatten().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def backward_scaled(loss_fn, model):
+    """(loss * S).backward() with S = 65536 for half (1 for bfloat16), halved while any gradient is non-finite.  Returns S."""
+    S = 65536.0 if ops.LP_IS_F16 else 1.0
+    while True:
+        for p in model.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        loss = loss_fn()
+        (loss * S).backward()
+        torch.cuda.synchronize()
+        ok = all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+        if ok or S <= 1.0:
+            return loss, S
+        S *= 0.5
+
+
+def golden_grads(model, z, S):
+    """worst / median rel-L2 over the gradient tensors that carry >= 1e-3 of the global norm, and the global norm's error
+    (the golden files hold `grad/<name>` -- whole tensors up to 8192 elements, every 7th element above -- and `gnorm/<name>`)."""
+    total = float(np.sqrt(sum(float(z[k]) ** 2 for k in z.files if k.startswith("gnorm/"))))
+    errs, sq = {}, 0.0
+    for k, p in model.named_parameters():
+        if f"gnorm/{k}" not in z.files:
+            continue
+        gn = float(z[f"gnorm/{k}"])
+        if p.grad is None:
+            continue
+        g = p.grad.double() / S
+        sq += float(g.pow(2).sum())
+        if gn < 1e-3 * total:
+            continue
+        ref = torch.from_numpy(z[f"grad/{k}"])
+        mine = g.cpu() if g.numel() <= 8192 else g.cpu().flatten()[::7]
+        errs[k] = rel(mine.reshape(ref.shape), ref)
+    v = sorted(errs.values())
+    return {"worst_grad": v[-1], "median_grad": v[len(v) // 2], "grad_norm": abs(sq ** 0.5 - total) / total}
+
+
+def case_small(out):
+    import tests.test_gpu_model as TM
+    z, cfg, P = TM.small(GOLDEN)
+    m = TM.build(cfg, P).train()
+    imgs, noise = torch.from_numpy(z["imgs"]).to(DEV), torch.from_numpy(z["noise"]).to(DEV)
+    keep = {}
+
+    def fwd():
+        (loss, fl), pred, mask = m(imgs, mask_ratio=float(z["mask_ratio"]), frame_loss=True, noise=noise)
+        keep["fl"], keep["pred"], keep["mask"] = fl, pred, mask
+        return loss
+
+    loss, S = backward_scaled(fwd, m)
+    assert torch.equal(keep["mask"].cpu(), torch.from_numpy(z["mask"]))
+    out["small/loss"] = abs(float(loss) - float(z["loss"])) / float(z["loss"])
+    out["small/pred"] = rel(keep["pred"], z["pred"])
+    out["small/frame_losses"] = rel(keep["fl"], z["frame_losses"])
+    for k, v in golden_grads(m, z, S).items():
+        out[f"small/{k}"] = v
+    out["small/loss_scale"] = S
+
+
+def case_mid(out):
+    import tests.test_gpu_model as TM
+    from oracle import mae3d_ref as O
+    cfg = O.MAEConfig(input_size=96, in_chans=1, embed_dim=256, depth=3, num_heads=4, decoder_embed_dim=128, decoder_depth=2,
+                      decoder_num_heads=4, num_frames=15, t_patch_size=3, pred_t_dim=15, high_res_input_size=192)
+    P = O.init_params(cfg, seed=3, bias_std=0.02)
+    imgs = torch.rand(3, 1, 15, 96, 96, generator=torch.Generator().manual_seed(1))
+    noise = torch.rand(3, cfg.num_patches, generator=torch.Generator().manual_seed(2))
+    loss_r, pred_r, mask_r, ids_r, grads_r = O.forward_backward(P, imgs, cfg, 0.75, noise)
+    m = TM.build(cfg, P)
+    keep = {}
+
+    def fwd():
+        loss, pred, mask = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
+        keep["pred"] = pred
+        return loss
+
+    loss, S = backward_scaled(fwd, m)
+    out["mid/loss"] = abs(float(loss) - float(loss_r)) / float(loss_r)
+    out["mid/pred"] = rel(keep["pred"], pred_r)
+    total = float(O.grad_norm(grads_r.values()))
+    errs = {k: rel(p.grad.double() / S, grads_r[k]) for k, p in m.named_parameters() if float(grads_r[k].norm()) >= 1e-3 * total}
+    v = sorted(errs.values())
+    out["mid/worst_grad"], out["mid/median_grad"] = v[-1], v[len(v) // 2]
+    out["mid/loss_scale"] = S
+
+
+def case_mae2d(out):
+    from functools import partial
+    from octcubem_amd import models_mae_2d
+    from oracle import vit_ref as V
+    z = np.load(os.path.join(GOLDEN, "mae2d_small.npz"))
+    cfg = V.MAE2DConfig(**json.loads(str(z["cfg"])))
+    P = V.mae2d_init(cfg, seed=int(z["param_seed"]))
+    m = models_mae_2d.MaskedAutoencoderViT(img_size=cfg.img_size, patch_size=cfg.patch_size, in_chans=cfg.in_chans,
+                                            embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
+                                            decoder_embed_dim=cfg.decoder_embed_dim, decoder_depth=cfg.decoder_depth,
+                                            decoder_num_heads=cfg.decoder_num_heads, mlp_ratio=4,
+                                            norm_layer=partial(torch.nn.LayerNorm, eps=1e-6))
+    m.load_state_dict(P, strict=True)
+    m = m.to(DEV)
+    imgs, noise = torch.from_numpy(z["imgs"]).to(DEV), torch.from_numpy(z["noise"]).to(DEV)
+    keep = {}
+
+    def fwd():
+        loss, pred, mask = m(imgs, mask_ratio=0.75, noise=noise)
+        keep["pred"] = pred
+        return loss
+
+    loss, S = backward_scaled(fwd, m)
+    out["mae2d_small/loss"] = abs(float(loss) - float(z["loss"])) / float(z["loss"])
+    out["mae2d_small/pred"] = rel(keep["pred"], z["pred"])
+    for k, v in golden_grads(m, z, S).items():
+        out[f"mae2d_small/{k}"] = v
+    out["mae2d_small/loss_scale"] = S
+
+
+def case_vit_st(out):
+    from functools import partial
+    from octcubem_amd import models_vit_st
+    from oracle import vit_ref as V
+    z = np.load(os.path.join(GOLDEN, "vit_st_small.npz"))
+    cfg = V.ViTSTConfig(**json.loads(str(z["cfg"])))
+    P = V.init_from_shapes(V.vit_st_param_shapes(cfg), seed=int(z["param_seed"]))
+    m = models_vit_st.VisionTransformer(
+        global_pool=True, num_frames=cfg.num_frames, t_patch_size=cfg.t_patch_size, img_size=cfg.img_size, patch_size=cfg.patch_size,
+        in_chans=cfg.in_chans, num_classes=cfg.num_classes, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
+        mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), sep_pos_embed=True, cls_embed=True)
+    m.load_state_dict(P, strict=True)
+    m = m.to(DEV).eval()
+    x = torch.from_numpy(z["x"]).to(DEV)
+    keep = {}
+
+    def fwd():
+        logits, emb = m(x, return_embeddings=True)
+        keep["logits"], keep["emb"] = logits, emb
+        return torch.nn.functional.cross_entropy(logits, torch.from_numpy(z["target"]).to(DEV))
+
+    loss, S = backward_scaled(fwd, m)
+    out["vit_st_small/logits"] = rel(keep["logits"], z["logits"])
+    out["vit_st_small/embedding"] = rel(keep["emb"], z["embedding"])
+    out["vit_st_small/loss"] = abs(float(loss) - float(z["loss"])) / float(z["loss"])
+    for k, v in golden_grads(m, z, S).items():
+        out[f"vit_st_small/{k}"] = v
+    out["vit_st_small/loss_scale"] = S
+
+
+def pin_grads(model, z, S):
+    """The full-size pins (oracle/gen_golden_fullsize.py): per-tensor gradient norms and strided samples of 20 tensors."""
+    names = json.loads(str(z["grad_names"]))
+    ref_norms = dict(zip(names, z["grad_norms"]))
+    total = float(z["global_grad_norm"])
+    params = dict(model.named_parameters())
+    sq, worst_norm = 0.0, 0.0
+    for k in names:
+        g = params[k].grad
+        gn = 0.0 if g is None else float(g.double().norm()) / S
+        sq += gn * gn
+        if ref_norms[k] >= 1e-3 * total:
+            worst_norm = max(worst_norm, abs(gn - ref_norms[k]) / ref_norms[k])
+    samples = []
+    for key in z.files:
+        if key.startswith("gsample/"):
+            k = key[len("gsample/"):]
+            if ref_norms[k] >= 1e-3 * total:
+                ref = torch.from_numpy(z[key])
+                samples.append(rel(params[k].grad.flatten()[::int(z[f"gstep/{k}"])][: ref.numel()].double() / S, ref))
+    return {"grad_norm": abs(sq ** 0.5 - total) / total, "worst_tensor_norm": worst_norm, "grad_samples_max": max(samples),
+            "grad_samples_median": float(np.median(samples))}
+
+
+def case_vitl(out):
+    """BASELINE config 2 at full size: ViT-L 3-D MAE on (1,1,60,256,256), forward and backward against the reference's pins."""
+    from octcubem_amd import models_mae
+    from oracle import mae3d_ref as O
+    z = np.load(os.path.join(GOLDEN, "vitl_bwd_pins.npz"))
+    pins = np.load(os.path.join(GOLDEN, "vitl_pins.npz"))
+    m = models_mae.octcube_vit_large_3dmae()
+    # forward pins (oracle/gen_golden.py: parameters of seed 0, volume seed 0): loss, 99 sampled elements of pred, its 2-norm
+    m.load_state_dict(O.init_params(O.VIT_L, seed=0), strict=True)
+    m = m.to(DEV)
+    imgs0 = torch.rand(1, 1, 60, 256, 256, generator=torch.Generator().manual_seed(0)).to(DEV)
+    torch.manual_seed(int(pins["noise_seed"]))
+    noise0 = torch.rand(1, 5120).to(DEV)
+    with torch.no_grad():
+        loss0, pred0, _ = m(imgs0, mask_ratio=0.75, noise=noise0)
+    assert torch.equal(m._ids_restore.cpu().int(), torch.from_numpy(pins["ids_restore"]))
+    out["vitl/loss"] = abs(float(loss0) - float(pins["loss"])) / float(pins["loss"])
+    out["vitl/pred_samples"] = rel(pred0.flatten()[torch.from_numpy(pins["pred_idx"]).to(DEV)], pins["pred_samples"])
+    out["vitl/pred_l2"] = abs(float(pred0.double().norm()) - float(pins["pred_l2"])) / float(pins["pred_l2"])
+    # backward pins (oracle/gen_golden_fullsize.py)
+    P = O.init_params(O.VIT_L, seed=int(z["param_seed"]), bias_std=float(z["param_bias_std"]))
+    m.load_state_dict({k: v.to(DEV) for k, v in P.items()}, strict=True)
+    m.train()
+    imgs = torch.rand(1, 1, 60, 256, 256, generator=torch.Generator().manual_seed(int(z["img_seed"]))).to(DEV)
+    torch.manual_seed(int(z["noise_seed"]))
+    noise = torch.rand(1, 5120).to(DEV)
+    keep = {}
+
+    def fwd():
+        loss, pred, mask = m(imgs, mask_ratio=float(z["mask_ratio"]), noise=noise)
+        keep["pred"] = pred
+        return loss
+
+    loss, S = backward_scaled(fwd, m)
+    out["vitl/bwd_loss"] = abs(float(loss) - float(z["loss"])) / float(z["loss"])
+    for k, v in pin_grads(m, z, S).items():
+        out[f"vitl/{k}"] = v
+    out["vitl/loss_scale"] = S
+
+
+def case_vit_st_l(out):
+    """BASELINE config 4 at full size: the ViT-L ST fine-tune model on (1,1,60,256,256), N = 5121, head_dim 64."""
+    from octcubem_amd import models_vit_st
+    from oracle import vit_ref as V
+    z = np.load(os.path.join(GOLDEN, "vit_st_l_pins.npz"))
+    cfg = V.ViTSTConfig(**json.loads(str(z["cfg"])))
+    P = V.init_from_shapes(V.vit_st_param_shapes(cfg), seed=int(z["param_seed"]), bias_std=float(z["param_bias_std"]))
+    m = models_vit_st.vit_large_patch16(num_frames=60, t_patch_size=3, img_size=256, in_chans=1, num_classes=8, global_pool=True,
+                                        sep_pos_embed=True, cls_embed=True, drop_path_rate=0.0)
+    m.load_state_dict(P, strict=True)
+    m = m.to(DEV).eval()
+    x = torch.rand(1, 1, 60, 256, 256, generator=torch.Generator().manual_seed(int(z["img_seed"]))).to(DEV)
+    keep = {}
+
+    def fwd():
+        logits, emb = m(x, return_embeddings=True)
+        keep["logits"], keep["emb"] = logits, emb
+        return torch.nn.functional.cross_entropy(logits, torch.from_numpy(z["target"]).to(DEV))
+
+    loss, S = backward_scaled(fwd, m)
+    out["vit_st_l/logits"] = rel(keep["logits"], z["logits"])
+    out["vit_st_l/embedding"] = rel(keep["emb"], z["embedding"])
+    out["vit_st_l/loss"] = abs(float(loss) - float(z["loss"])) / float(z["loss"])
+    for k, v in pin_grads(m, z, S).items():
+        out[f"vit_st_l/{k}"] = v
+    out["vit_st_l/loss_scale"] = S
+
+
+CASES = {"small": case_small, "mid": case_mid, "mae2d_small": case_mae2d, "vit_st_small": case_vit_st, "vitl": case_vitl,
+         "vit_st_l": case_vit_st_l}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--cases", default=",".join(CASES))
+    ap.add_argument("--min-fill", type=float, default=0.0, help="ops.ATTN_BWD_FUSED_MIN_FILL (0: the fused backward, as the GPU tests run)")
+    a = ap.parse_args()
+    from octcubem_amd import _lib
+    ops.ATTN_BWD_FUSED_MIN_FILL = a.min_fill
+    out = {}
+    for c in a.cases.split(","):
+        CASES[c](out)
+        torch.cuda.empty_cache()
+    res = {"lib": _lib.LIB_PATH, "lp_dtype": str(ops.BF16), "min_fill": a.min_fill, "entries": out}
+    with open(a.out, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -31,6 +31,25 @@ def test_library_exports_every_declared_symbol():
     assert lib.octmae_abi_version() == _lib.expected_abi_version() and lib.octmae_mt_chunk_elems() == 65536
 
 
+def test_half_build_exports_the_same_abi_and_reports_its_operand_type():
+    """liboctmae_f16.so (make F16=1; the verification build of tests/test_gpu_f16_parity.py) is the SAME source: every declared
+    symbol, the same ABI number, octmae_lp_dtype() == 1 where the product library says 0; and the host side maps that to the torch
+    dtype it allocates 16-bit buffers with (in a child process: a process binds ONE library)."""
+    import subprocess
+    from octcubem_amd import _lib
+    path = os.path.join(ROOT, "octcubem_amd", "liboctmae_f16.so")
+    assert os.path.exists(path), "make -C octcubem_amd/csrc both"
+    lib = ctypes.CDLL(path)
+    for s in declared_symbols():
+        assert hasattr(lib, s), s
+    assert lib.octmae_abi_version() == _lib.expected_abi_version()
+    assert lib.octmae_lp_dtype() == 1 and _lib.load().octmae_lp_dtype() == 0
+    code = "from octcubem_amd import ops; print(ops.BF16, ops.LP_IS_F16, ops.ATTN_OPTIMISTIC)"
+    for lp, want in ((path, "torch.float16 True False"), (_lib.LIB_PATH, "torch.bfloat16 False True")):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, OCTMAE_LIB=lp))
+        assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == want, (r.stdout, r.stderr)
+
+
 def test_argument_errors_are_reported_without_a_gpu():
     from octcubem_amd import _lib
     lib = _lib.load()

@@ -183,7 +183,9 @@ SHIPPED_CFG = {
                  "drop_rate": 0.0, "global_pool": True, "vit_model_name": "ViT_flash_attn", "model_ckpt": ""}}
 
 
-def test_full_size_config5_step_vs_reference_pins(golden_dir):
+# both attention-backward dispatches (see tests/test_gpu_fullsize_pins.py): 2 pairs x 16 heads do not fill the chip either
+@pytest.mark.parametrize("dispatch", ["fused", pytest.param("fill_rule", marks=pytest.mark.small_batch_rule)])
+def test_full_size_config5_step_vs_reference_pins(golden_dir, dispatch):
     """BASELINE config 5 at FULL size on one GPU: the shipped tower config (ViT-L ST tower on (2,1,60,256,256), N = 5121 tokens,
     + ViT-L 2-D tower on (2,3,224,224), embed 512) through coem.create_model_from_config, one contrastive step, against pins
     produced by the reference's own tower classes and its own ClipLoss (oracle/gen_golden_coem_full.py: features, loss,
@@ -194,7 +196,9 @@ def test_full_size_config5_step_vs_reference_pins(golden_dir):
     summation order inside the LayerNorm reductions (1e-7 on the features) moved the tower gradient norm from 4.5e-3 to 8.5e-3 and
     the loss from 7.4e-4 to 9.2e-4 between two builds of round 4."""
     import json, os
+    from octcubem_amd import ops
     from tests.conftest import parity
+    assert ops.attn_bwd_use_fused(2, 16, 64, DEV) == (dispatch == "fused")
     z = np.load(os.path.join(golden_dir, "coem_l_pins.npz"))
     model = coem.create_model_from_config(json.loads(json.dumps(SHIPPED_CFG)), flash_semantics=False)
     PA = V.init_from_shapes(V.vit_st_param_shapes(V.ViTSTConfig(**json.loads(str(z["cfg_a"])))), seed=int(z["seed_a"]))

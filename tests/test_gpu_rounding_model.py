@@ -199,14 +199,19 @@ def test_whole_mae_step_matches_the_rounding_point_model_to_1e_3(case, golden_di
     ws = max(sens, key=sens.get)
     print(f"[model vs itself, parameters perturbed 1e-7, {case}] pred {sens_pred:.2e}, gradients: worst {ws} {sens[ws]:.2e}, "
           f"median {sorted(sens.values())[len(sens) // 2]:.2e}")
+    # Every "2 x the model's own sensitivity" bound has an ABSOLUTE ceiling, and the sensitivities themselves are bounded at 2 x what
+    # was measured (pred 3.6e-3 ... 3.9e-3, median gradient 9.6e-4 ... 1.8e-3, worst gradient tensor 1.2e-2 ... 1.7e-2): a model that
+    # became more chaotic -- or a sensitivity probe that broke -- fails here instead of widening the bound.
+    CEIL = 1.5e-2
     parity(f"rp_model/{case}/loss", e_loss, 1e-3)
-    parity(f"rp_model/{case}/pred", e_pred, max(1e-3, 2.0 * sens_pred))
-    parity(f"rp_model/{case}/pred_self_sensitivity", sens_pred, 1.0)
-    parity(f"rp_model/{case}/worst_grad", errs[worst], max(2e-3, 2.0 * sens[worst]))
+    parity(f"rp_model/{case}/pred", e_pred, min(max(1e-3, 2.0 * sens_pred), CEIL))
+    parity(f"rp_model/{case}/pred_self_sensitivity", sens_pred, 8e-3)
+    parity(f"rp_model/{case}/worst_grad", errs[worst], min(max(2e-3, 2.0 * sens[worst]), CEIL))
+    parity(f"rp_model/{case}/worst_grad_self_sensitivity", max(sens.values()), 3.5e-2)
     parity(f"rp_model/{case}/median_grad", sorted(errs.values())[len(errs) // 2], 2e-3)
-    parity(f"rp_model/{case}/median_grad_self_sensitivity", sorted(sens.values())[len(sens) // 2], 1.0)
+    parity(f"rp_model/{case}/median_grad_self_sensitivity", sorted(sens.values())[len(sens) // 2], 4e-3)
     bad = {k: (v, sens[k]) for k, v in errs.items()
-           if v > max(2e-3 if ("norm" in k and k.endswith(("weight", "bias"))) else 1e-3, 2.0 * sens[k])}
+           if v > min(max(2e-3 if ("norm" in k and k.endswith(("weight", "bias"))) else 1e-3, 2.0 * sens[k]), CEIL)}
     assert not bad, bad
     assert all(v <= 1e-3 for v in small_abs.values()), small_abs
     # and what the same quantities are against the PLAIN fp32 oracle (no roundings): the distance test_gpu_model.py tolerates
