@@ -380,6 +380,8 @@ def main():
         break
     if not args.no_kernel_timing:
         ops.KTIMER = ops.KernelTimer()
+    if reducer is not None:
+        reducer.timing = True       # device events around every gradient chunk's exchange and around finish()'s wait (timed steps only)
     board = BoardSampler(local_rank) if rank == 0 else None
     if board is not None:
         board.start()
@@ -389,6 +391,18 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     board_stats = board.stop() if board is not None else None
+    comm_timing = None
+    if reducer is not None:
+        reducer.timing = False
+        comm_timing = reducer.timing_summary(last=1)
+        # the slowest rank's wait is the step's exposed communication: MAX over ranks through the same backend
+        if comm_timing is not None:
+            if comm is not None:
+                comm_timing["exposed_ms_per_step_max_over_ranks"] = comm.all_reduce_scalar(comm_timing["exposed_ms_per_step"], ocomm.MAX)
+            elif use_dist:
+                t = torch.tensor([comm_timing["exposed_ms_per_step"]], dtype=torch.float64, device="cpu" if args.gloo_one_gpu else dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                comm_timing["exposed_ms_per_step_max_over_ranks"] = float(t.item())
     # device memory of this rank's step (caching-allocator peak since process start: the timed steps and the warm-ups are the same
     # step); what one volume of the micro-batch holds decides whether 128 fits in 288 GB
     peak_alloc, peak_reserved = torch.cuda.max_memory_allocated(dev), torch.cuda.max_memory_reserved(dev)
@@ -513,7 +527,17 @@ def main():
                 red["chunk_mb"] = [round(4 * (e - s_) / 1e6, 1) for s_, e in reducer.bounds]
                 red["cold_chunk"] = [bool(c) for c in reducer.cold_chunk]
                 red["transport"] = reducer.transport
+            ct = comm_timing or {}
             out["comm"] = {"backend": comm_kind, "ranks_seen": ranks_seen, "agreed_micro_batch": mb, "reducer": red,
+                           # What the optimizer waited for the exchange: the compute stream's idle time inside reducer.finish(), HIP
+                           # events on the compute stream (rank 0; ..._max_over_ranks: the slowest rank), mean over the timed steps.
+                           # timeline: the last timed step's chunks in launch order, ms after begin_backward() -- ready = gradients
+                           # final on the compute stream, done = collective complete on the communication stream.
+                           "exposed_ms_per_step": ct.get("exposed_ms_per_step"), "exposed_ms_max": ct.get("exposed_ms_max"),
+                           "exposed_ms_per_step_max_over_ranks": ct.get("exposed_ms_per_step_max_over_ranks"),
+                           "exposed_frac_of_step": (ct["exposed_ms_per_step_max_over_ranks"] / (1e3 * dt / args.steps))
+                           if ct.get("exposed_ms_per_step_max_over_ranks") is not None else None,
+                           "last_micro_step_backward_ms": ct.get("backward_ms_per_step"), "timeline": ct.get("timeline"),
                            # ranks see different volumes (seed + rank), so their last-step losses differ slightly; identical
                            # weights after the exchange keep them within sampling noise of each other
                            "last_loss_min_max_over_ranks": list(loss_minmax)}

@@ -24,7 +24,7 @@ extern "C" {
  * from this header and refuses a library that reports another number, __graft_entry__.build() and the tests compare the two.
  * 4: octmae_attn_bwd_dq_rowconst.  5: octmae_comm_* (RCCL), octmae_attn_bwd_fused + workspace query.  7: octmae_set_option, octmae_scatter_add_rows, octmae_dec_assemble_bwd.
  * 8: octmae_linear_dgrad_delta, octmae_attn_bwd_fused_delta.  9: octmae_wgrad_accum_pair, octmae_wgrad_split_plan.
- * 10: octmae_lp_dtype. */
+ * 10: octmae_lp_dtype, octmae_comm_stream, octmae_mt_adamw_fused. */
 #define OCTMAE_ABI_VERSION 10
 int octmae_abi_version(void);
 
@@ -231,6 +231,15 @@ int octmae_mt_finish_norm(const float* sumsq, int ntensors, float max_norm, floa
 int octmae_mt_adamw(const void* tensor_table, const int* chunk_tensor, const long long* chunk_off, int nchunks,
                     const float* gscale, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                     void* stream);
+/* The same update with two optional by-products of the one pass it makes over the parameters and gradients (both may be NULL):
+ *   lp_table  device array of one pointer per tensor of the table: where to write the 16-bit operand copy (octmae_lp_dtype) of the
+ *             UPDATED parameter, NULL entries skipped -- replaces the per-forward cast of the whole parameter arena
+ *             (the bf16 weights autocast re-derives per forward in the reference, engine_pretrain.py:110);
+ *   sumsq     fp32 [ntensors], += sum of squares of the RAW gradient per tensor (before gscale): get_grad_norm_
+ *             (custom_util/misc.py:356-373) without its own pass over the gradients; finish with octmae_mt_finish_norm. */
+int octmae_mt_adamw_fused(const void* tensor_table, const int* chunk_tensor, const long long* chunk_off, int nchunks,
+                          const float* gscale, void* const* lp_table, float* sumsq, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int step, void* stream);
 
 /* ---- data-parallel exchange over RCCL (xGMI) -----------------------------------------------------------
  * What the reference gets from torch.distributed's NCCL backend on this path:
@@ -265,6 +274,10 @@ int octmae_comm_allgather_async(void* comm, const void* send, void* recv, long l
 int octmae_comm_reduce_scatter_async(void* comm, const void* send, void* recv, long long count_per_rank, int dtype, int op,
                                      void* after_stream);
 int octmae_comm_wait(void* comm, void* stream);
+/* The communication stream itself (a hipStream_t written to *stream_out), for MEASUREMENT only: the host side records timing
+ * events on it around a collective (bench.py's exposed-communication fields; DDP offers the same through its logging hooks,
+ * torch/nn/parallel/distributed.py `_get_ddp_logging_data`).  Nothing may be enqueued on it that a collective would wait for. */
+int octmae_comm_stream(void* comm, void** stream_out);
 
 /* ---- hardware layout probes (tests only: pin the MFMA / ds_read_b64_tr_b16 lane maps the kernels assume) */
 int octmae_probe_mfma32(const void* a_frag_bf16, const void* b_frag_bf16, float* d_regs, void* stream);

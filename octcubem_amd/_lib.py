@@ -53,6 +53,7 @@ SIGNATURES = {
     "octmae_mt_sumsq": [_vp, _vp, _vp, _i, _vp, _vp],
     "octmae_mt_finish_norm": [_vp, _i, _f, _vp, _vp, _vp],
     "octmae_mt_adamw": [_vp, _vp, _vp, _i, _vp, _f, _f, _f, _f, _f, _i, _vp],
+    "octmae_mt_adamw_fused": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _vp],
     "octmae_comm_available": [],
     "octmae_comm_unique_id": [_vp],
     "octmae_comm_init": [_vp, _vp, _i, _i, _i],
@@ -64,6 +65,7 @@ SIGNATURES = {
     "octmae_comm_allgather_async": [_vp, _vp, _vp, _ll, _i, _vp],
     "octmae_comm_reduce_scatter_async": [_vp, _vp, _vp, _ll, _i, _i, _vp],
     "octmae_comm_wait": [_vp, _vp],
+    "octmae_comm_stream": [_vp, _vp],
     "octmae_probe_mfma32": [_vp, _vp, _vp, _vp],
     "octmae_probe_trread": [_vp, _vp, _vp],
 }

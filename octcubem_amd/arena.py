@@ -11,8 +11,10 @@ operands, refreshed by a single cast kernel per forward) and one fp32 gradient b
 """
 from __future__ import annotations
 
+import os
 import re
-from typing import Dict, List, Tuple
+import weakref
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -20,6 +22,20 @@ import torch.nn as nn
 from . import ops
 
 ALIGN = 64  # elements; keeps every tensor 256-byte (fp32) / 128-byte (bf16) aligned
+# OCTMAE_ALWAYS_REFRESH_LP=1: cast the whole arena before every forward, as until round 4 (the escape hatch for code that edits
+# weights behind PyTorch's back -- through ``.data`` -- which no version counter sees)
+ALWAYS_REFRESH_LP = os.environ.get("OCTMAE_ALWAYS_REFRESH_LP", "0") == "1"
+
+_OWNER: Dict[int, tuple] = {}      # id(param) -> (weakref(param), weakref(arena)): which arena a parameter lives in
+
+
+def arena_of(p) -> Optional["ParamArena"]:
+    """The arena that owns ``p`` right now (its data is that arena's view), or None."""
+    ent = _OWNER.get(id(p))
+    if ent is None or ent[0]() is not p:
+        return None
+    ar = ent[1]()
+    return ar if ar is not None and ar.owns(p) else None
 
 
 def _ordered(named: List[Tuple[str, nn.Parameter]]) -> List[Tuple[str, nn.Parameter]]:
@@ -79,6 +95,12 @@ class ParamArena:
                     g.copy_(p.grad)
                 p.grad = g if p.requires_grad else None
                 self.offset[id(p)] = o
+                _OWNER[id(p)] = (weakref.ref(p), weakref.ref(self))
+        if len(_OWNER) > 4096:           # entries of collected parameters
+            for k in [k for k, (r, a) in _OWNER.items() if r() is None or a() is None]:
+                del _OWNER[k]
+        self._lp_state = None
+        self.root = lambda: None          # weakref to the module that bound this arena (bind_arena)
         self.refresh_lp()
 
     # ------------------------------------------------------------------
@@ -107,8 +129,27 @@ class ParamArena:
                     g.zero_()
                 p.grad = g
 
-    def refresh_lp(self):
+    def _versions(self) -> int:
+        # in-place writes to a parameter (optimizers of torch.optim, load_state_dict, p.copy_ / p.add_ under no_grad, the
+        # logit-scale clamp of the contrastive step) bump ITS version counter -- the arena's own tensor does not see them
+        return sum(p._version for _, p, _, _ in self.entries)
+
+    def refresh_lp(self, force: bool = False):
+        """Bring the 16-bit operand copy up to date with the fp32 master weights: one cast pass over the arena (6 B per parameter)
+        -- skipped when nothing has written the parameters since the last pass except FusedAdamW, whose kernel writes the copy of
+        what it updates itself (octmae_mt_adamw_fused).  "Nothing" = the sum of the parameters' PyTorch version counters."""
+        vs = self._versions()
+        if not (force or ALWAYS_REFRESH_LP) and self._lp_state == vs:
+            return
         ops.cast_bf16_into(self.flat, self.lp)
+        self._lp_state = vs
+
+    def invalidate_lp(self):
+        """The next forward re-casts the whole arena (call after writing weights through ``.data`` or raw pointers)."""
+        self._lp_state = None
+
+    def lp_ptr(self, p: nn.Parameter) -> int:
+        return self.lp.data_ptr() + self.lp.element_size() * self.offset[id(p)]
 
     def zero_grad(self):
         self.grad.zero_()
@@ -150,12 +191,19 @@ def get_arena(module: nn.Module, full_check: bool = False) -> ParamArena:
             p = next(module.parameters(), None)
             ok = p is None or arena.owns(p)
         if ok:
+            # A building block used on its own (a Block / create_block() inside somebody else's model: seams 1 and 2 of SURVEY 8b)
+            # is the root of its own small arena and nobody calls prepare() for it: its operand copy follows the master weights
+            # here (a dozen version counters; until round 4 it was cast once, at binding, and went stale with the first optimizer
+            # step).  Blocks inside this package's models are refreshed once per forward by the model's prepare().
+            if not full_check and arena.root() is module:
+                arena.refresh_lp()
             return arena
     return bind_arena(module)
 
 
 def bind_arena(root: nn.Module) -> ParamArena:
     arena = ParamArena(root)
+    arena.root = weakref.ref(root)
     for m in root.modules():
         object.__setattr__(m, "_arena", arena)
         if hasattr(m, "_views"):

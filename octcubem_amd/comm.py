@@ -117,6 +117,14 @@ class NativeComm:
              self._stream())
         self._keep += [send, recv]
 
+    def torch_stream(self):
+        """The communication stream as a torch stream object, for timing events only (octmae_comm_stream)."""
+        if getattr(self, "_tstream", None) is None:
+            h = C.c_void_p()
+            call("octmae_comm_stream", self._h, C.byref(h))
+            self._tstream = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", self.device))
+        return self._tstream
+
     def wait(self):
         """The current torch stream waits for every collective enqueued so far."""
         call("octmae_comm_wait", self._h, self._stream())

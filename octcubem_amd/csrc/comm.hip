@@ -258,6 +258,12 @@ extern "C" int octmae_comm_reduce_scatter_async(void* comm, const void* send, vo
   return 0;
 }
 
+extern "C" int octmae_comm_stream(void* comm, void** stream_out) {
+  if (!comm || !stream_out) return -1;
+  *stream_out = reinterpret_cast<void*>(reinterpret_cast<Comm*>(comm)->stream);
+  return 0;
+}
+
 extern "C" int octmae_comm_wait(void* comm, void* stream) {
   if (!comm) return -1;
   Comm* c = reinterpret_cast<Comm*>(comm);

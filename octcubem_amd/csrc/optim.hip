@@ -79,10 +79,16 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
   p -= (a.lr / a.bc1) * (m / denom);
 }
 
-// g is multiplied by *gscale (clip coefficient and/or 1/loss-scale) before use
+// g is multiplied by *gscale (clip coefficient and/or 1/loss-scale) before use.
+// LP: also write the 16-bit operand copy of the updated parameter (lp_table[t], the arena's mirror: the per-forward cast pass over
+// the whole arena -- 6 B per parameter -- becomes 2 B written here).  SQ: also accumulate sumsq[t] += sum(g^2) of the RAW gradient
+// (get_grad_norm_ without its own pass over the gradients; only when no clip coefficient has to be known before the update).
+template <bool LP, bool SQ>
 __global__ __launch_bounds__(256) void mt_adamw_kernel(const TensorDesc* __restrict__ tensors, const int* __restrict__ chunk_tensor,
                                                        const long long* __restrict__ chunk_off, const float* __restrict__ gscale,
+                                                       bf16_t* const* __restrict__ lp_table, float* __restrict__ sumsq,
                                                        const AdamArgs a) {
+  __shared__ float red[4];
   const int t = chunk_tensor[blockIdx.x];
   const long long off = chunk_off[blockIdx.x];
   const TensorDesc d = tensors[t];
@@ -92,9 +98,12 @@ __global__ __launch_bounds__(256) void mt_adamw_kernel(const TensorDesc* __restr
   const float* g = d.g + off;
   float* m = d.m + off;
   float* v = d.v + off;
+  bf16_t* lp = LP ? lp_table[t] : nullptr;
+  if (LP && lp) lp += off;
   const float gs = gscale ? *gscale : 1.f;
+  float s = 0.f;
   const bool vec = (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
-                      reinterpret_cast<uintptr_t>(v)) & 15) == 0);
+                      reinterpret_cast<uintptr_t>(v)) & 15) == 0) && (!LP || (reinterpret_cast<uintptr_t>(lp) & 7) == 0);
   long long done = 0;
   if (vec) {
     const long long n4 = n >> 2;
@@ -103,6 +112,7 @@ __global__ __launch_bounds__(256) void mt_adamw_kernel(const TensorDesc* __restr
       const f32x4 gv = *reinterpret_cast<const f32x4*>(g + 4 * i);
       f32x4 mv = *reinterpret_cast<f32x4*>(m + 4 * i);
       f32x4 vv = *reinterpret_cast<f32x4*>(v + 4 * i);
+      if (SQ) s += (gv[0] * gv[0] + gv[1] * gv[1]) + (gv[2] * gv[2] + gv[3] * gv[3]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float pe = pv[e], me = mv[e], ve = vv[e];
@@ -112,13 +122,26 @@ __global__ __launch_bounds__(256) void mt_adamw_kernel(const TensorDesc* __restr
       *reinterpret_cast<f32x4*>(p + 4 * i) = pv;
       *reinterpret_cast<f32x4*>(m + 4 * i) = mv;
       *reinterpret_cast<f32x4*>(v + 4 * i) = vv;
+      if (LP && lp) {
+        u32x2 w = {pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};
+        *reinterpret_cast<u32x2*>(lp + 4 * i) = w;
+      }
     }
     done = n4 << 2;
   }
   for (long long i = done + threadIdx.x; i < n; i += 256) {
     float pe = p[i], me = m[i], ve = v[i];
-    adam_one(pe, g[i] * gs, me, ve, a);
+    const float ge = g[i];
+    if (SQ) s += ge * ge;
+    adam_one(pe, ge * gs, me, ve, a);
     p[i] = pe; m[i] = me; v[i] = ve;
+    if (LP && lp) lp[i] = f2bf(pe);
+  }
+  if (SQ) {
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(sumsq + t, (red[0] + red[1]) + (red[2] + red[3]));
   }
 }
 
@@ -145,16 +168,28 @@ extern "C" int octmae_mt_finish_norm(const float* sumsq, int ntensors, float max
   return 0;
 }
 
-extern "C" int octmae_mt_adamw(const void* tensor_table, const int* chunk_tensor, const long long* chunk_off, int nchunks,
-                               const float* gscale, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                               void* stream) {
+extern "C" int octmae_mt_adamw_fused(const void* tensor_table, const int* chunk_tensor, const long long* chunk_off, int nchunks,
+                                     const float* gscale, void* const* lp_table, float* sumsq, float lr, float beta1, float beta2,
+                                     float eps, float weight_decay, int step, void* stream) {
   OCTMAE_CHECK_ARG(tensor_table && chunk_tensor && chunk_off && nchunks > 0 && step >= 1);
   AdamArgs a;
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
   a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-  hipLaunchKernelGGL(mt_adamw_kernel, dim3(nchunks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const TensorDesc*>(tensor_table), chunk_tensor, chunk_off, gscale, a);
+  const TensorDesc* tt = reinterpret_cast<const TensorDesc*>(tensor_table);
+  bf16_t* const* lpt = reinterpret_cast<bf16_t* const*>(lp_table);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (lpt && sumsq) hipLaunchKernelGGL((mt_adamw_kernel<true, true>), dim3(nchunks), dim3(256), 0, st, tt, chunk_tensor, chunk_off, gscale, lpt, sumsq, a);
+  else if (lpt) hipLaunchKernelGGL((mt_adamw_kernel<true, false>), dim3(nchunks), dim3(256), 0, st, tt, chunk_tensor, chunk_off, gscale, lpt, sumsq, a);
+  else if (sumsq) hipLaunchKernelGGL((mt_adamw_kernel<false, true>), dim3(nchunks), dim3(256), 0, st, tt, chunk_tensor, chunk_off, gscale, lpt, sumsq, a);
+  else hipLaunchKernelGGL((mt_adamw_kernel<false, false>), dim3(nchunks), dim3(256), 0, st, tt, chunk_tensor, chunk_off, gscale, lpt, sumsq, a);
   OCTMAE_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int octmae_mt_adamw(const void* tensor_table, const int* chunk_tensor, const long long* chunk_off, int nchunks,
+                               const float* gscale, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                               void* stream) {
+  return octmae_mt_adamw_fused(tensor_table, chunk_tensor, chunk_off, nchunks, gscale, nullptr, nullptr, lr, beta1, beta2, eps,
+                               weight_decay, step, stream);
 }

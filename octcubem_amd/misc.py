@@ -178,6 +178,12 @@ class NativeScalerWithGradNormCount:
         if clip_grad is not None:
             assert parameters is not None
         if not self.enabled:
+            if clip_grad is None and isinstance(optimizer, _optim.FusedAdamW) and optimizer._grad_scale is None \
+                    and frozenset(id(p) for p in params if p.grad is not None) == optimizer.grads_key():
+                # no coefficient has to be known before the update and the norm is asked of exactly the gradients the optimizer
+                # consumes: the AdamW kernels accumulate it in the pass they make over the gradients anyway
+                _, norm = optimizer.step(want_norm=True)
+                return norm
             norm, coef = _optim.grad_norm_and_coef(params, clip_grad, _norm_cache)
             if isinstance(optimizer, _optim.FusedAdamW):
                 optimizer.set_grad_scale(coef if clip_grad is not None else None)

@@ -120,6 +120,8 @@ class MaskedAutoencoderViT(nn.Module):
             torch.nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
             torch.nn.init.normal_(self.mask_token, std=0.02)
         self.apply(self._init_weights)
+        if getattr(self, "_arena", None) is not None:      # re-initialised after binding: the line above wrote through ``.data``
+            self._arena.invalidate_lp()
 
     def _init_weights(self, m):
         if isinstance(m, nn.Linear):

@@ -90,6 +90,8 @@ class MaskedAutoencoderViT(nn.Module):
         torch.nn.init.normal_(self.cls_token, std=0.02)
         torch.nn.init.normal_(self.mask_token, std=0.02)
         self.apply(self._init_weights)
+        if getattr(self, "_arena", None) is not None:      # re-initialised after binding: the line above wrote through ``.data``
+            self._arena.invalidate_lp()
 
     def _init_weights(self, m):
         if isinstance(m, nn.Linear):

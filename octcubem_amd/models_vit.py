@@ -82,7 +82,7 @@ class VisionTransformer(nn.Module):
         if self._ids is None or self._ids.shape[0] != N or self._ids.device != x.device:
             object.__setattr__(self, "_ids", torch.arange(L, device=x.device, dtype=torch.int64).expand(N, L).contiguous())
         pe = self.pos_embed[0]
-        x = ops.EncAssembleFn.apply(tok, pe[1:], self.cls_token, pe[:1].view(1, 1, -1), self._ids)      # fp32 [N, 1 + L, D]
+        x = ops.EncAssembleFn.apply(tok, pe[1:], self.cls_token, pe[:1].view(1, 1, -1), self._ids, self._ids)      # fp32 [N, 1 + L, D]; identity permutation: deterministic table gradient
         for blk in self.blocks:
             x = blk(x)
         if self.global_pool:

@@ -85,7 +85,9 @@ class VisionTransformer(nn.Module):
         pos = (self.pos_embed_spatial.repeat(1, T, 1) + torch.repeat_interleave(self.pos_embed_temporal, h * w, dim=1)).view(L, -1)
         if self._ids is None or self._ids.shape[0] != N or self._ids.device != x.device:
             object.__setattr__(self, "_ids", torch.arange(L, device=x.device, dtype=torch.int64).expand(N, L).contiguous())
-        x = ops.EncAssembleFn.apply(tok, pos, self.cls_token, self.pos_embed_class, self._ids)   # fp32 [N, 1+L, C]
+        # every token kept, in order: the identity is its own inverse permutation, which selects the deterministic gather for the
+        # positional table's gradient (octmae_scatter_add_rows) instead of ATen's atomic index_add_
+        x = ops.EncAssembleFn.apply(tok, pos, self.cls_token, self.pos_embed_class, self._ids, self._ids)   # fp32 [N, 1+L, C]
         hidden_states_list = []
         residual = None
         for i, blk in enumerate(self.blocks):

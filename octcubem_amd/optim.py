@@ -7,6 +7,7 @@ driver (main_pretrain_oph_joint_2d512_flash_attn.py:441-455): same param_groups 
 """
 from __future__ import annotations
 
+import os
 import struct
 from typing import List, Optional
 
@@ -17,9 +18,10 @@ from .ops import _stream
 
 
 class _MultiTensorTable:
-    """Device-side tables for a list of (p, g, m, v) tensors: octmae_mt_* calling convention."""
+    """Device-side tables for a list of (p, g, m, v) tensors: octmae_mt_* calling convention.  ``lps``: per tensor the device
+    address of the 16-bit operand copy of p (0: none) -- the optional table octmae_mt_adamw_fused writes through."""
 
-    def __init__(self, ps: List[torch.Tensor], gs, ms, vs):
+    def __init__(self, ps: List[torch.Tensor], gs, ms, vs, lps=None):
         from ._lib import load
         chunk = load().octmae_mt_chunk_elems()
         dev = ps[0].device
@@ -36,6 +38,9 @@ class _MultiTensorTable:
         self.table = torch.frombuffer(raw, dtype=torch.uint8).clone().to(dev)
         self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=dev)
         self.chunk_off = torch.tensor(co, dtype=torch.int64, device=dev)
+        self.lp_table = None
+        if lps is not None and any(lps):
+            self.lp_table = torch.tensor([int(a) for a in lps], dtype=torch.int64, device=dev)
         # every pointer the table holds is part of its identity: a loaded optimizer state replaces exp_avg / exp_avg_sq
         self.key = tuple((p.data_ptr(), g.data_ptr() if g is not None else 0, m.data_ptr() if m is not None else 0,
                           v.data_ptr() if v is not None else 0) for p, g, m, v in zip(ps, gs, ms, vs))
@@ -68,6 +73,9 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._tables = {}
         self._grad_scale: Optional[torch.Tensor] = None   # device scalar multiplied into every gradient
+        # write_mirror: the AdamW kernel also writes the 16-bit operand copy (arena.ParamArena.lp) of every parameter it updates, so
+        # the next forward needs no cast pass over the arena (OCTMAE_ADAMW_MIRROR=0: same-box A/B; the arena then re-casts)
+        self.write_mirror = os.environ.get("OCTMAE_ADAMW_MIRROR", "1") != "0"
 
     def load_state_dict(self, state_dict):
         """The moment buffers are replaced: drop the device pointer tables (they are rebuilt on the next step)."""
@@ -103,9 +111,18 @@ class FusedAdamW(torch.optim.Optimizer):
                 start, end = o, o + n
         base[start:end].zero_()
 
+    def grads_key(self):
+        """Identity of the set of gradients a step() will consume (misc.NativeScalerWithGradNormCount compares it with the set it is
+        asked to take the norm of before it lets the optimizer produce that norm itself)."""
+        return frozenset(id(p) for g in self.param_groups for p in g["params"] if p.grad is not None)
+
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, want_norm: bool = False):
+        """want_norm: also return the 2-norm of the (raw, un-scaled) gradients this step consumed, accumulated by the AdamW kernels
+        themselves (one read of the gradients for norm and update) -> (loss, norm) instead of loss."""
+        from . import arena as _arena
         loss = closure() if closure is not None else None
+        sumsq = None
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
@@ -127,13 +144,30 @@ class FusedAdamW(torch.optim.Optimizer):
             key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
                          self.state[p]["exp_avg_sq"].data_ptr()) for p in ps)
             tab = self._tables.get(gi)
-            if tab is None or tab.key != key:
+            if tab is None or tab.key != key or tab.mirror != self.write_mirror:
+                owners = [_arena.arena_of(p) for p in ps]
+                lps = [(a.lp_ptr(p) if (a is not None and self.write_mirror) else 0) for a, p in zip(owners, ps)]
                 tab = _MultiTensorTable([p.data for p in ps], [p.grad for p in ps], [self.state[p]["exp_avg"] for p in ps],
-                                        [self.state[p]["exp_avg_sq"] for p in ps])
+                                        [self.state[p]["exp_avg_sq"] for p in ps], lps)
+                tab.mirror = self.write_mirror
+                # arenas whose parameters this group updates WITHOUT writing their operand copy: they must re-cast
+                tab.stale_arenas = [a for a in {id(a): a for a, lp in zip(owners, lps) if a is not None and lp == 0}.values()]
                 self._tables[gi] = tab
+            for a in tab.stale_arenas:
+                a.invalidate_lp()
+            if want_norm and sumsq is None:
+                n_max = max(len([p for p in g["params"] if p.grad is not None]) for g in self.param_groups)
+                sumsq = torch.zeros((len(self.param_groups), max(n_max, 1)), dtype=torch.float32, device=ps[0].device)
             b1, b2 = group["betas"]
             gs = self._grad_scale
-            call("octmae_mt_adamw", tab.table.data_ptr(), tab.chunk_tensor.data_ptr(), tab.chunk_off.data_ptr(), tab.n_chunks,
-                 gs.data_ptr() if gs is not None else None, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+            call("octmae_mt_adamw_fused", tab.table.data_ptr(), tab.chunk_tensor.data_ptr(), tab.chunk_off.data_ptr(), tab.n_chunks,
+                 gs.data_ptr() if gs is not None else None, tab.lp_table.data_ptr() if tab.lp_table is not None else None,
+                 sumsq[gi].data_ptr() if sumsq is not None else None, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                  float(group["weight_decay"]), int(group["_step"]), _stream())
-        return loss
+        if not want_norm:
+            return loss
+        if sumsq is None:
+            return loss, torch.tensor(0.0)
+        out = torch.empty(2, dtype=torch.float32, device=sumsq.device)
+        call("octmae_mt_finish_norm", sumsq.data_ptr(), sumsq.numel(), 0.0, out.data_ptr(), out.data_ptr() + 4, _stream())
+        return loss, out[0]

@@ -75,6 +75,13 @@ class FlatGradReducer:
         self._order_now: List[int] = []
         self.stats = {"launched_in_backward": 0, "launched_in_finish": 0, "bytes_in_finish": 0, "bytes_total": 0,
                       "last_launch_bytes": 0}
+        # Measurement (bench.py): with timing = True every exchanged step leaves device events behind -- backward begin, per chunk
+        # "gradients final on the compute stream" / "collective complete on the communication stream", and the two ends of
+        # finish()'s wait on the compute stream -- resolved by timing_summary().  What the optimizer WAITED for the exchange
+        # (the compute stream idle between the end of backward and the completion of the last collective) is the exposed
+        # communication of the step; DDP reports the same quantity through its logging data.  Off: no events, no cost.
+        self.timing = False
+        self._tl_steps: List = []
 
     # ------------------------------------------------------------------ layout
     def _layout(self, rebuild: bool = False):
@@ -144,6 +151,9 @@ class FlatGradReducer:
         self._reports = {}
         self._order_now = []
         self._overlap_now = self._sync and self.overlap and not (self.multi_use and self._expected is None)
+        self._tl = None
+        if self.timing and self._sync:
+            self._tl = {"b0": self._event_now(), "chunks": [], "host_wait_ms": 0.0}
         ops.add_grad_ready_callback(self, self._on_ready if self._overlap_now else self._on_ready_note)
         if self._overlap_now and self._frozen:
             # chunks made only of parameters that never report (zeros in the arena) are exchanged NOW, under the whole backward
@@ -187,6 +197,46 @@ class FlatGradReducer:
                 if self._remaining[c] == 0:
                     self._launch(c)
 
+    # ------------------------------------------------------------------ measurement
+    def _event_now(self, stream=None):
+        """A timing event recorded now on `stream` (default: the current stream); None on the CPU."""
+        if self._arena is None or not self._arena.grad.is_cuda:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream) if stream is not None else ev.record()
+        return ev
+
+    def _comm_torch_stream(self):
+        return self.comm.torch_stream() if self.comm is not None else self._comm_stream
+
+    def timing_summary(self, last: int = 1):
+        """Resolve the events of the exchanged steps recorded so far (synchronises the device).  Returns
+        {"steps": n, "exposed_ms_per_step": mean wait of the compute stream in finish(), "exposed_ms_max": ...,
+         "backward_ms_per_step": begin_backward() -> finish() on the compute stream,
+         "timeline": for each of the `last` steps the chunks in launch order:
+                     {chunk, mb, cold, in_finish, ready_ms, done_ms} relative to begin_backward(), plus finish_begin_ms / finish_end_ms}."""
+        steps = self._tl_steps
+        if not steps:
+            return None
+        if self._arena.grad.is_cuda:
+            torch.cuda.synchronize(self._arena.grad.device)
+        exposed, bwd, lines = [], [], []
+        for st in steps:
+            if st["b0"] is None:           # CPU transport: host wall-clock of the waits
+                exposed.append(st["host_wait_ms"])
+                continue
+            exposed.append(st["f0"].elapsed_time(st["f1"]))
+            bwd.append(st["b0"].elapsed_time(st["f0"]))
+        for st in steps[-last:]:
+            if st["b0"] is None:
+                continue
+            lines.append({"finish_begin_ms": round(st["b0"].elapsed_time(st["f0"]), 3), "finish_end_ms": round(st["b0"].elapsed_time(st["f1"]), 3),
+                          "chunks": [{"chunk": c, "mb": round(nb / 1e6, 1), "cold": bool(self.cold_chunk[c]) if c < len(self.cold_chunk) else None,
+                                      "in_finish": fin, "ready_ms": round(st["b0"].elapsed_time(r), 3), "done_ms": round(st["b0"].elapsed_time(d), 3)}
+                                     for c, nb, fin, r, d in st["chunks"]]})
+        return {"steps": len(steps), "exposed_ms_per_step": sum(exposed) / len(exposed), "exposed_ms_max": max(exposed),
+                "backward_ms_per_step": (sum(bwd) / len(bwd)) if bwd else None, "timeline": lines}
+
     def _launch(self, c: int):
         if self._launched[c]:
             return
@@ -211,15 +261,21 @@ class FlatGradReducer:
         else:
             self.stats["launched_in_finish"] += 1
             self.stats["bytes_in_finish"] += nbytes
+        tl = getattr(self, "_tl", None)
+        ready = self._event_now() if (tl is not None and buf.is_cuda) else None
         if self.comm is not None:
             from . import comm as C
             self.comm.all_reduce_async(buf, C.AVG if self.average else C.SUM)
+            if ready is not None:
+                tl["chunks"].append((c, nbytes, not self._in_backward, ready, self._event_now(self.comm.torch_stream())))
         elif buf.is_cuda:
             self._comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._comm_stream):
                 work = dist.all_reduce(buf, op=dist.ReduceOp.AVG if self.average else dist.ReduceOp.SUM, group=self.group,
                                        async_op=True)
             self._pending.append(work)
+            if ready is not None:
+                tl["chunks"].append((c, nbytes, not self._in_backward, ready, self._event_now(self._comm_stream)))
         else:
             if self.average:
                 buf.mul_(1.0 / self.world)      # gloo has no AVG
@@ -236,6 +292,11 @@ class FlatGradReducer:
         if not self._sync:
             self._reports = {}
             return
+        tl = getattr(self, "_tl", None)
+        if tl is not None:
+            import time
+            tl["f0"] = self._event_now()
+            t_host = time.perf_counter()
         for c in range(len(self.bounds)):
             self._launch(c)
         if self.comm is not None:
@@ -245,6 +306,13 @@ class FlatGradReducer:
         if self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
         self._pending = []
+        if tl is not None:
+            tl["host_wait_ms"] = 1e3 * (time.perf_counter() - t_host)
+            tl["f1"] = self._event_now()
+            self._tl_steps.append(tl)
+            if len(self._tl_steps) > 64:
+                del self._tl_steps[0]
+            self._tl = None
         if self.multi_use and self._expected is None:
             self._expected = dict(self._reports)
         self._reports = {}

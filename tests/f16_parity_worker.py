@@ -24,6 +24,8 @@ if ROOT not in sys.path:
 from octcubem_amd import ops  # noqa: E402
 
 DEV = "cuda"
+SCALE0 = 65536.0        # torch.cuda.amp.GradScaler's init_scale; --scale0 2**24 finds the largest finite scale (its steady state)
+NAMES = {}              # label -> the tensor a "worst" entry refers to
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
@@ -34,7 +36,7 @@ def rel(a, b):
 
 def backward_scaled(loss_fn, model):
     """(loss * S).backward() with S = 65536 for half (1 for bfloat16), halved while any gradient is non-finite.  Returns S."""
-    S = 65536.0 if ops.LP_IS_F16 else 1.0
+    S = SCALE0 if ops.LP_IS_F16 else 1.0
     while True:
         for p in model.parameters():
             if p.grad is not None:
@@ -48,7 +50,7 @@ def backward_scaled(loss_fn, model):
         S *= 0.5
 
 
-def golden_grads(model, z, S):
+def golden_grads(model, z, S, label=""):
     """worst / median rel-L2 over the gradient tensors that carry >= 1e-3 of the global norm, and the global norm's error
     (the golden files hold `grad/<name>` -- whole tensors up to 8192 elements, every 7th element above -- and `gnorm/<name>`)."""
     total = float(np.sqrt(sum(float(z[k]) ** 2 for k in z.files if k.startswith("gnorm/"))))
@@ -67,6 +69,7 @@ def golden_grads(model, z, S):
         mine = g.cpu() if g.numel() <= 8192 else g.cpu().flatten()[::7]
         errs[k] = rel(mine.reshape(ref.shape), ref)
     v = sorted(errs.values())
+    NAMES[f"{label}/worst_grad"] = sorted(errs, key=errs.get)[-3:]
     return {"worst_grad": v[-1], "median_grad": v[len(v) // 2], "grad_norm": abs(sq ** 0.5 - total) / total}
 
 
@@ -87,7 +90,7 @@ def case_small(out):
     out["small/loss"] = abs(float(loss) - float(z["loss"])) / float(z["loss"])
     out["small/pred"] = rel(keep["pred"], z["pred"])
     out["small/frame_losses"] = rel(keep["fl"], z["frame_losses"])
-    for k, v in golden_grads(m, z, S).items():
+    for k, v in golden_grads(m, z, S, "small").items():
         out[f"small/{k}"] = v
     out["small/loss_scale"] = S
 
@@ -115,6 +118,7 @@ def case_mid(out):
     total = float(O.grad_norm(grads_r.values()))
     errs = {k: rel(p.grad.double() / S, grads_r[k]) for k, p in m.named_parameters() if float(grads_r[k].norm()) >= 1e-3 * total}
     v = sorted(errs.values())
+    NAMES["mid/worst_grad"] = sorted(errs, key=errs.get)[-3:]
     out["mid/worst_grad"], out["mid/median_grad"] = v[-1], v[len(v) // 2]
     out["mid/loss_scale"] = S
 
@@ -144,7 +148,7 @@ def case_mae2d(out):
     loss, S = backward_scaled(fwd, m)
     out["mae2d_small/loss"] = abs(float(loss) - float(z["loss"])) / float(z["loss"])
     out["mae2d_small/pred"] = rel(keep["pred"], z["pred"])
-    for k, v in golden_grads(m, z, S).items():
+    for k, v in golden_grads(m, z, S, "mae2d_small").items():
         out[f"mae2d_small/{k}"] = v
     out["mae2d_small/loss_scale"] = S
 
@@ -174,7 +178,7 @@ def case_vit_st(out):
     out["vit_st_small/logits"] = rel(keep["logits"], z["logits"])
     out["vit_st_small/embedding"] = rel(keep["emb"], z["embedding"])
     out["vit_st_small/loss"] = abs(float(loss) - float(z["loss"])) / float(z["loss"])
-    for k, v in golden_grads(m, z, S).items():
+    for k, v in golden_grads(m, z, S, "vit_st_small").items():
         out[f"vit_st_small/{k}"] = v
     out["vit_st_small/loss_scale"] = S
 
@@ -279,15 +283,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
     ap.add_argument("--cases", default=",".join(CASES))
+    ap.add_argument("--scale0", type=float, default=SCALE0, help="initial loss scale of the half build (halved while a gradient is non-finite)")
     ap.add_argument("--min-fill", type=float, default=0.0, help="ops.ATTN_BWD_FUSED_MIN_FILL (0: the fused backward, as the GPU tests run)")
     a = ap.parse_args()
     from octcubem_amd import _lib
     ops.ATTN_BWD_FUSED_MIN_FILL = a.min_fill
+    global SCALE0
+    SCALE0 = a.scale0
     out = {}
     for c in a.cases.split(","):
         CASES[c](out)
         torch.cuda.empty_cache()
-    res = {"lib": _lib.LIB_PATH, "lp_dtype": str(ops.BF16), "min_fill": a.min_fill, "entries": out}
+    res = {"lib": _lib.LIB_PATH, "lp_dtype": str(ops.BF16), "min_fill": a.min_fill, "scale0": SCALE0, "entries": out, "names": NAMES}
     with open(a.out, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res))

@@ -71,6 +71,7 @@ def _worker(rank, world, port, q):
     out["frozen"] = bool(red._frozen and id(arena.params[5]) in red._cold)
     arena.grad.zero_()
     b0, f0 = red.stats["launched_in_backward"], red.stats["launched_in_finish"]
+    red.timing = True                      # the measurement bench.py switches on for its timed steps (host clock on the CPU)
     red.begin_backward(sync=True)
     out["early_launches"] = red.stats["launched_in_backward"] - b0
     try:
@@ -84,6 +85,8 @@ def _worker(rank, world, port, q):
     red.finish()
     out["finish_launches"] = red.stats["launched_in_finish"] - f0
     out["grad_frozen"] = arena.grad.clone()
+    red.timing = False
+    out["timing"] = red.timing_summary()
     # --- autograd-hook route (PyTorch-side parameters): backward through real autograd.  Only three parameters take part: a
     # different control flow from the steps above, so every rank calls relearn() first (without it the launch-order check
     # of the frozen layout raises, see test_control_flow_divergence_raises_instead_of_hanging)
@@ -128,6 +131,9 @@ def test_flat_grad_reducer_gloo_world2():
     for o in outs:
         assert o["frozen"] and o["early_launches"] >= 1 and o["late_raises"] and o["finish_launches"] == 0, \
             {k: o[k] for k in ("frozen", "early_launches", "late_raises", "finish_launches")}
+        # one exchanged step was recorded with timing on: its wait (host clock over gloo) is reported, non-negative and finite
+        t = o["timing"]
+        assert t["steps"] == 1 and 0.0 <= t["exposed_ms_per_step"] < 1e4 and t["exposed_ms_max"] >= t["exposed_ms_per_step"], t
     for i, (off, n) in enumerate(a["offsets"]):
         exp = torch.zeros(n) if i == 5 else torch.full((n,), 1.5)
         assert torch.allclose(a["grad_frozen"][off:off + n], exp) and torch.equal(a["grad_frozen"], b["grad_frozen"]), i

@@ -663,3 +663,96 @@ def test_small_batches_take_the_two_kernel_attention_backward(golden_dir, monkey
         gn = float(z[f"gnorm/{k}"])
         if gn >= 1e-3 * total:
             assert abs(float(p.grad.double().norm()) - gn) <= 1.5e-2 * gn, k
+
+
+def test_operand_copy_follows_the_master_weights_through_every_kind_of_update(golden_dir):
+    """The 16-bit operand copy of the parameter arena is no longer cast before every forward: FusedAdamW's kernel writes the copy of
+    what it updates (octmae_mt_adamw_fused) and the arena re-casts only when a parameter's PyTorch version counter moved.  After each
+    kind of update the copy must equal a fresh cast of the master weights BIT FOR BIT at the next forward."""
+    from octcubem_amd import ops as _ops
+    z, cfg, P = small(golden_dir)
+    m = build(cfg, P).train()
+    imgs, noise = torch.from_numpy(z["imgs"]).to(DEV), torch.from_numpy(z["noise"]).to(DEV)
+    opt = foptim.FusedAdamW(misc.add_weight_decay(m, 0.05), lr=1e-3, betas=(0.9, 0.95))
+    scaler = misc.NativeScalerWithGradNormCount()
+
+    def fresh():
+        return _ops.cast_bf16(m.arena.flat)
+
+    def step(clip=None):
+        opt.zero_grad()
+        loss, _, _ = m(imgs, mask_ratio=0.75, noise=noise)
+        assert torch.equal(m.arena.lp, fresh()), "operand copy stale at forward time"
+        return scaler(loss, opt, parameters=m.parameters(), clip_grad=clip)
+
+    casts = []
+    real = _ops.cast_bf16_into
+    _ops.cast_bf16_into = lambda s_, d_: (casts.append(s_.numel()), real(s_, d_))[1]
+    try:
+        n1 = step()                                          # fused norm + update + copy in one pass
+        assert torch.equal(m.arena.lp, fresh())              # written by the AdamW kernel
+        c0 = len(casts)
+        n2 = step(clip=1.0)                                  # separate norm pass (the clip coefficient must be known first)
+        assert len(casts) == c0, "a step of FusedAdamW alone must not trigger a re-cast of the arena"
+        assert torch.equal(m.arena.lp, fresh())
+        assert float(n1) > 0 and float(n2) > 0 and torch.isfinite(n1) and torch.isfinite(n2)
+        with torch.no_grad():                                # a foreign in-place update (torch.optim, EMA, clamp ...)
+            m.decoder_pred.weight.mul_(1.5)
+        assert not torch.equal(m.arena.lp, fresh())
+        c0 = len(casts)
+        step()
+        assert len(casts) == c0 + 1                          # seen through the version counter: exactly one re-cast
+        sd = {k: v.clone() * 0.5 for k, v in m.state_dict().items()}
+        m.load_state_dict(sd, strict=True)
+        step()
+        assert torch.equal(m.arena.lp, fresh())
+        opt.write_mirror = False                             # the A/B switch: AdamW without the copy -> the arena re-casts
+        c0 = len(casts)
+        step(); step()                                       # (each forward inside step() asserts a fresh copy)
+        assert len(casts) == c0 + 1
+        loss, _, _ = m(imgs, mask_ratio=0.75, noise=noise)
+        assert len(casts) == c0 + 2 and torch.equal(m.arena.lp, fresh())
+    finally:
+        _ops.cast_bf16_into = real
+
+
+def test_fused_norm_equals_the_separate_norm_pass(golden_dir):
+    """NativeScalerWithGradNormCount without clipping lets the AdamW kernels accumulate the gradient norm; it must be the number the
+    separate multi-tensor pass (get_grad_norm_) returns for the same gradients, and the update must be the same update."""
+    z, cfg, P = small(golden_dir)
+    imgs, noise = torch.from_numpy(z["imgs"]).to(DEV), torch.from_numpy(z["noise"]).to(DEV)
+    res = {}
+    for mode in ("fused", "separate"):
+        m = build(cfg, P).train()
+        opt = foptim.FusedAdamW(misc.add_weight_decay(m, 0.05), lr=1e-3, betas=(0.9, 0.95))
+        opt.zero_grad()
+        loss, _, _ = m(imgs, mask_ratio=0.75, noise=noise)
+        if mode == "fused":
+            norm = misc.NativeScalerWithGradNormCount()(loss, opt, parameters=m.parameters())
+        else:
+            loss.backward()
+            norm = misc.get_grad_norm_(m.parameters())
+            opt.step()
+        res[mode] = (float(norm), {k: p.detach().clone() for k, p in m.named_parameters()})
+    assert abs(res["fused"][0] - res["separate"][0]) <= 1e-6 * res["separate"][0], (res["fused"][0], res["separate"][0])
+    for k, p in res["fused"][1].items():
+        assert torch.equal(p, res["separate"][1][k]), k
+
+
+def test_a_block_used_on_its_own_follows_a_foreign_optimizer():
+    """Seam 2 of SURVEY 8(b): video_vit.Block inside somebody else's model, trained by torch.optim.  The Block is the root of its own
+    parameter arena; its operand copy must follow every update (until round 4 it was cast once, when the arena was bound)."""
+    from functools import partial
+    from octcubem_amd import video_vit
+    torch.manual_seed(0)
+    blk = video_vit.Block(128, 2, mlp_ratio=4.0, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6)).to(DEV).train()
+    x = torch.randn(2, 65, 128, device=DEV)
+    opt = torch.optim.SGD(blk.parameters(), lr=0.5)
+    y0 = blk(x).detach().clone()
+    blk(x).square().mean().backward()
+    opt.step()
+    y1 = blk(x).detach().clone()
+    assert not torch.equal(y0, y1), "the Block did not see the optimizer's update"
+    twin = video_vit.Block(128, 2, mlp_ratio=4.0, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6))
+    twin.load_state_dict({k: v.detach().cpu().clone() for k, v in blk.state_dict().items()})
+    assert torch.equal(twin.to(DEV).train()(x), y1)
