@@ -242,7 +242,8 @@ def main():
             ops.ATTN_BWD_FUSED[int(k[len("ops.ATTN_BWD_FUSED"):])] = bool(int(v))
         elif k.startswith("ops."):
             assert hasattr(ops, k[4:]), k
-            setattr(ops, k[4:], bool(int(v)))
+            old = getattr(ops, k[4:])      # the value takes the type of the switch it replaces (bool through int: "0" / "1")
+            setattr(ops, k[4:], bool(int(v)) if isinstance(old, bool) else type(old)(v))
         else:
             ops.set_option(k, int(v))
     comm = None

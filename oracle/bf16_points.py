@@ -36,6 +36,47 @@ LOG2E = 1.4426950408889634
 # that is how tests/test_oracle_rounding_model.py pins the model (its hand-written backward formulas included) to the fp64
 # autograd of oracle/mae3d_ref.py, which is itself pinned to the reference's golden vectors.
 _EXACT = False
+# The 16-bit type the rounding points round to: bfloat16 (the shipped library) or float16 (`with operand_type(torch.float16)`: the
+# model of the half verification build, liboctmae_f16.so -- same rounding points, 3 more mantissa bits).
+LP_DTYPE = torch.bfloat16
+
+
+class operand_type:
+    """Context manager: the 16-bit type of every rounding point (torch.bfloat16 | torch.float16)."""
+
+    def __init__(self, dtype):
+        assert dtype in (torch.bfloat16, torch.float16)
+        self.dtype = dtype
+
+    def __enter__(self):
+        global LP_DTYPE
+        self.prev, LP_DTYPE = LP_DTYPE, self.dtype
+        return self
+
+    def __exit__(self, *a):
+        global LP_DTYPE
+        LP_DTYPE = self.prev
+
+
+LP_BITS = None      # not None: round to this many significant bits with an UNBOUNDED exponent instead of to LP_DTYPE
+
+
+class operand_bits:
+    """Context manager: every rounding point keeps `bits` significant bits (8 = bfloat16's, 11 = half's) and any exponent -- the
+    arithmetic of the half build under loss scaling (nothing underflows), and the tool that shows how each quantity's error scales
+    with the operand epsilon (tests/test_oracle_rounding_model.py)."""
+
+    def __init__(self, bits: int):
+        self.bits = int(bits)
+
+    def __enter__(self):
+        global LP_BITS
+        self.prev, LP_BITS = LP_BITS, self.bits
+        return self
+
+    def __exit__(self, *a):
+        global LP_BITS
+        LP_BITS = self.prev
 
 
 class exact_arithmetic:
@@ -53,7 +94,12 @@ class exact_arithmetic:
 
 def bf(x: torch.Tensor) -> torch.Tensor:
     """Round to bfloat16 (nearest even) and return as float64."""
-    return x.to(D) if _EXACT else x.to(torch.float32).to(torch.bfloat16).to(D)
+    if _EXACT:
+        return x.to(D)
+    if LP_BITS is not None:
+        m, e = torch.frexp(x.to(torch.float32).to(D))
+        return torch.ldexp(torch.round(m * 2.0 ** LP_BITS) / 2.0 ** LP_BITS, e)
+    return x.to(torch.float32).to(LP_DTYPE).to(D)
 
 
 def f32(x: torch.Tensor) -> torch.Tensor:

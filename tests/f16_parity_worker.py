@@ -280,6 +280,7 @@ CASES = {"small": case_small, "mid": case_mid, "mae2d_small": case_mae2d, "vit_s
 
 
 def main():
+    global SCALE0
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
     ap.add_argument("--cases", default=",".join(CASES))
@@ -288,7 +289,6 @@ def main():
     a = ap.parse_args()
     from octcubem_amd import _lib
     ops.ATTN_BWD_FUSED_MIN_FILL = a.min_fill
-    global SCALE0
     SCALE0 = a.scale0
     out = {}
     for c in a.cases.split(","):
