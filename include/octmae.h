@@ -24,7 +24,7 @@ extern "C" {
  * from this header and refuses a library that reports another number, __graft_entry__.build() and the tests compare the two.
  * 4: octmae_attn_bwd_dq_rowconst.  5: octmae_comm_* (RCCL), octmae_attn_bwd_fused + workspace query.  7: octmae_set_option, octmae_scatter_add_rows, octmae_dec_assemble_bwd.
  * 8: octmae_linear_dgrad_delta, octmae_attn_bwd_fused_delta.  9: octmae_wgrad_accum_pair, octmae_wgrad_split_plan.
- * 10: octmae_lp_dtype, octmae_comm_stream, octmae_mt_adamw_fused. */
+ * 10: octmae_lp_dtype, octmae_comm_stream, octmae_mt_adamw_fused, octmae_gemm_bf16_ws + the stream-K workspace arguments. */
 #define OCTMAE_ABI_VERSION 10
 int octmae_abi_version(void);
 
@@ -48,6 +48,9 @@ int octmae_lp_dtype(void);
  *                          1: on v_mfma_f32_16x16x32_bf16 (gemm256q_kernel: same tile, staging and epilogues; 3 % faster alone,
  *                          no faster in the training step -- DESIGN.md section 4).  Bit 11 (0x800) of octmae_gemm_bf16's
  *                          `epilogue` argument forces the 32x32x16 form for one call (bits 8-10: tile / main-loop variants)
+ *   "gemm_streamk"         1 (default): stream-K over a partial last round of the 256-tile forward / dgrad GEMMs when a workspace is
+ *                          lent (octmae_gemm_bf16_ws); 0: never; 2: for every partial last round (measurements)
+ *   "gemm_streamk_launches" read-only: returns how many GEMM launches of this process took the stream-K kernel (tests)
  *   "wgrad_stagger"        v >= 0 (default 29): split-K weight gradients of >= 8 slices with <= 96 k-tiles each run with slice
  *                          lengths rising by v / 256 k-tiles per output tile of the launch from one slice to the next, so that the
  *                          slices' fp32-atomic epilogues follow one another instead of colliding; 0: equal slices */
@@ -72,6 +75,23 @@ int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2, const floa
                      int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided, int b_kstrided,
                      int epilogue, int splitk, void* stream);
 
+/* octmae_gemm_bf16 with a stream-K workspace lent for this one call (also the trailing `sk_ws, sk_ws_bytes` of the three fused
+ * entry points below; NULL / 0 = never stream-K).  The reference's cuBLAS / hipBLASLt picks stream-K kernels by itself for such
+ * shapes (nn.Linear forward and backward: video_vit.py:114-135, timm Mlp).  The 256-tile forward / dgrad kernels run one output
+ * tile per workgroup, in rounds of the CU count; when the last round would be 1/8 ... 80 % full (nt = 2.52 x 256 tiles for a
+ * 1024-column Linear over the token rows of 32 volumes: what one rank of an 8-GPU step runs) -- or when there are fewer tiles than
+ * CUs at all (small batches) -- the first CU-count workgroups share the k-tiles of those last tiles evenly instead: fp32 partial
+ * tiles travel through `sk_ws` to the workgroup that owns the tile (it holds the tile's first k-tile), which adds them to its
+ * accumulators and runs the SAME fused epilogue.  Results differ from the plain launch only by the order of those fp32 additions
+ * (deterministic: the split is a function of the shape alone).  sk_ws: octmae_gemm_streamk_ws_kib() KiB of device memory whose
+ * last CU-count dwords (the flags) were ZERO when it was first used; contents need not be preserved between calls, but two launches
+ * that may run CONCURRENTLY (different streams) must not share one workspace.  octmae_set_option("gemm_streamk", 0) switches the
+ * planning off (1 default; 2: every partial last round -- measurements). */
+int octmae_gemm_streamk_ws_kib(void);     /* size of that workspace in KiB for the current device */
+int octmae_gemm_bf16_ws(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
+                        int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided, int b_kstrided,
+                        int epilogue, int splitk, void* sk_ws, long long sk_ws_bytes, void* stream);
+
 /* Backward of epilogue 2 together with fc1's bias gradient, WITHOUT atomics (timm Mlp backward: fc2 dgrad, nn.GELU backward,
  * fc1.bias.grad; video_vit.py:174-179 under autograd):
  *   dX bf16 [M][K] = (dY[M][N] @ W[N][K]) * gelu'(pre[M][K]),   bias_grad[K] += column sums of dX   (bias_grad may be NULL).
@@ -83,7 +103,8 @@ int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2, const floa
  * and sum the columns of dX in a separate pass.  small_tile: kernel-selection bits as in octmae_linear_resid_rowscale, 0 = automatic. */
 int octmae_dgelu_colsum_ws_rows(int M);
 int octmae_linear_dgrad_dgelu(const void* W, const void* dY, void* dX, const void* pre, float* ws, float* bias_grad,
-                              int M, int N, int K, int ldw, int ldy, int ldx, int ldpre, int small_tile, void* stream);
+                              int M, int N, int K, int ldw, int ldy, int ldx, int ldpre, int small_tile, void* sk_ws,
+                              long long sk_ws_bytes, void* stream);
 
 /* Two weight gradients over the SAME token rows in one launch (the fc1 / fc2 and the qkv / proj Linears of a Block; backward of
  * video_vit.py:114-135 and timm Mlp under autograd):
@@ -111,14 +132,14 @@ int octmae_wgrad_split_plan(int M, int splitk, int tiles, int* slices, int* boun
  * backward reads).  Returns -2 when the problem does not take the 256-tile kernel (M or K < 256, N % 64 != 0, K % 8 != 0): the
  * caller then uses octmae_gemm_bf16 and octmae_attn_bwd_fused.  variant: kernel-selection bits (bit 8 forces "not applicable"). */
 int octmae_linear_dgrad_delta(const void* W, const void* dY, void* dX, const void* O, float* delta, int M, int N, int K, int ldw,
-                              int ldy, int ldx, int ldo, int H, int hd, int variant, void* stream);
+                              int ldy, int ldx, int ldo, int H, int hd, int variant, void* sk_ws, long long sk_ws_bytes, void* stream);
 
 /* Stochastic depth (timm DropPath around both Block branches, video_vit.py:181-184 with drop_path > 0; fine-tune drivers use
  * 0.1-0.2): out f32 [M][N] = res + rowscale[m / rows_per_scale] * (X[M][K] @ W[N][K]^T + bias) -- the per-sample keep mask
  * (0 or 1/keep_prob) applied to the branch inside the residual epilogue.  nn.Linear layouts; small_tile: the kernel-selection bits of `epilogue` above (0x100 / 0x200 / 0x400), 0 = automatic. */
 int octmae_linear_resid_rowscale(const void* W, const void* X, float* out, const float* bias, const float* res,
                                  const float* rowscale, int rows_per_scale, int N, int M, int K, int ldw, int ldx, int ldout,
-                                 int ldres, int small_tile, void* stream);
+                                 int ldres, int small_tile, void* sk_ws, long long sk_ws_bytes, void* stream);
 
 /* ---- LayerNorm over the fp32 residual stream ---------------------------------------------------
  * nn.LayerNorm(eps=1e-6): models_mae_joint_res_flash_attn.py:799, video_vit.py:161,172,181-184, :489, :592.

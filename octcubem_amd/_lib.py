@@ -19,6 +19,8 @@ SIGNATURES = {
     "octmae_lp_dtype": [],
     "octmae_set_option": [C.c_char_p, _i],
     "octmae_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "octmae_gemm_bf16_ws": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp],
+    "octmae_gemm_streamk_ws_kib": [],
     "octmae_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "octmae_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "octmae_layernorm_bwd_ws_floats": [_i, _i],
@@ -34,11 +36,11 @@ SIGNATURES = {
     "octmae_random_masking_ids": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "octmae_cast_f32_bf16": [_vp, _vp, _ll, _vp],
     "octmae_cast_rowscale_f32_bf16": [_vp, _vp, _vp, _ll, _i, _i, _vp],
-    "octmae_linear_resid_rowscale": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "octmae_linear_resid_rowscale": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp],
     "octmae_colsum_accum": [_vp, _i, _vp, _i, _i, _i, _vp],
     "octmae_dgelu_colsum_ws_rows": [_i],
-    "octmae_linear_dgrad_dgelu": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "octmae_linear_dgrad_delta": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "octmae_linear_dgrad_dgelu": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp],
+    "octmae_linear_dgrad_delta": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp],
     "octmae_wgrad_split_plan": [_i, _i, _i, _vp, _vp],
     "octmae_wgrad_accum_pair": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "octmae_patch_gather": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

@@ -741,18 +741,91 @@ __device__ __forceinline__ void glds16(const gi32x4& rsrc, unsigned lds_addr, un
 #pragma clang diagnostic pop
 }
 
-// the tile body: tile t of p, k slice kz of S   (smem: [stage 2][operand 2][half 2] x 16 KiB)
-template <bool A_KS, bool B_KS, int EPI, bool OUT_AB>
-__device__ __forceinline__ void gemm256p_body(const GemmParams& p, const int t, const int kz, const int S, char* smem) {
-  const int tid = threadIdx.x, lane = tid & 63;
+// ---- stream-K (gemm256p_sk_kernel below): a workgroup computes a SEGMENT of a tile's k range.  The segment that holds the tile's
+// first k-tile OWNS the tile: it gathers the fp32 partial tiles of the others ("peers": the workgroups next in line, each of which
+// computes its share of this tile FIRST), adds them to its accumulators and runs the epilogue.  A peer leaves its 256 x 256 fp32
+// partial in its own slot of a caller-owned workspace (lane-contiguous 16-byte stores, 8 KiB per store instruction) and raises the
+// slot's flag to the launch's generation number (visibility across CUs / XCDs: see sk_publish below).
+struct SkSeg {
+  int mode;               // 0 whole tile (no hand-off), 1 peer (publish the partial), 2 owner (gather `npeers` partials first)
+  int slot;               // mode 1: this workgroup's slot
+  int peer0, npeers;      // mode 2: slots peer0 .. peer0 + npeers - 1
+  float* slots;           // [G][65536] fp32
+  unsigned* flags;        // [G]
+  unsigned gen;           // generation of this launch (flags are never reset: a stale flag holds an older generation)
+};
+constexpr int SK_SLOT_FLOATS = T2 * T2;
+
+// The partial tiles travel by WRITE-THROUGH (`sc1`) 16-byte stores and `sc1` loads, the flag by an `sc1` store and an `sc1` poll
+// (MI355X_MICROARCH.md, table of hand-offs measured with sc1 loads in place of the acquire, first row: one lane of the storing
+// workgroup signals for all its stores after every storing wave's vmcnt(0) and a workgroup barrier; the polling wave loads after its
+// poll has matched, the others after a workgroup barrier it then joins; hipMalloc memory; one workgroup per CU).  The first version
+// used plain stores + an agent-scope release / acquire pair: each release (buffer_wbl2) writes back the XCD's whole L2 -- full of
+// the other 31 workgroups' partial tiles and of streamed GEMM outputs -- and the 32 of them per XCD ran one after the other:
+// +135 us per launch whatever its size (tools/streamk_ab.py, profiles/r05_streamk_ab.txt).
+constexpr int SK_AUX = 16;      // sc1
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_rsrc(const SkSeg& sk, int slot) {
+  const unsigned long long q = reinterpret_cast<unsigned long long>(sk.slots) + (unsigned long long)slot * SK_SLOT_FLOATS * 4;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)q), hi = __builtin_amdgcn_readfirstlane((unsigned)(q >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, SK_SLOT_FLOATS * 4, 0x00020000);
+}
+
+__device__ __forceinline__ void sk_publish(const SkSeg& sk, f32x16 (&acc)[4][2], int tid) {
+  const __amdgpu_buffer_rsrc_t rs = sk_rsrc(sk, sk.slot);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (((i * 2 + j) * 4 + q) * 512 + tid) * 16, 0, SK_AUX);
+      }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its stores have been written through
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(sk.flags + sk.slot, sk.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // global_store sc1
+}
+
+__device__ __forceinline__ void sk_gather(const SkSeg& sk, f32x16 (&acc)[4][2], int tid) {
+  for (int n = 0; n < sk.npeers; ++n) {
+    const int s = sk.peer0 + n;
+    if (tid == 0) {
+      while (__hip_atomic_load(sk.flags + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.gen) __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = sk_rsrc(sk, s);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        u32x4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (((i * 2 + j) * 4 + q) * 512 + tid) * 16, 0, SK_AUX);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 f = __builtin_bit_cast(f32x4, v[q]);
+          acc[i][j][4 * q] += f[0]; acc[i][j][4 * q + 1] += f[1]; acc[i][j][4 * q + 2] += f[2]; acc[i][j][4 * q + 3] += f[3];
+        }
+        __builtin_amdgcn_sched_barrier(0);        // 16 registers of loads in flight at a time, not all 128
+      }
+  }
+}
+
+// the tile body: tile t of p, k-tiles kt0 .. kt1 - 1   (smem: [stage 2][operand 2][half 2] x 16 KiB); partial = split-K (atomics)
+template <bool A_KS, bool B_KS, int EPI, bool OUT_AB, bool SK = false>
+__device__ __forceinline__ void gemm256p_body(const GemmParams& p, const int t, const int kt0, const int kt1, const bool partial,
+                                              char* smem, const SkSeg* sk = nullptr) {
+  int tid_ = threadIdx.x;
+  // stream-K calls this body in a loop over the segments of a workgroup's span: without this the compiler hoists every lane-derived
+  // address of the body (fragment offsets, DMA offsets, the epilogue's) out of that loop and keeps them alive across the k-loop --
+  // 270 spilled registers, whose scratch traffic would sit inside the hand-counted vmcnt ring
+  if constexpr (SK) asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wid >> 2, wb = wid & 3;          // wa = 1: the late group (waves 4-7)
   int ta, tb;
   tile_coord(p, t, ta, tb);
   const int a0 = ta * T2, b0 = tb * T2;
-
-  int kt0, kt1;
-  split_range(p, kz, S, kt0, kt1);
   const int nk = kt1 - kt0;
 
   f32x16 acc[4][2];
@@ -909,8 +982,14 @@ __device__ __forceinline__ void gemm256p_body(const GemmParams& p, const int t, 
       }
     }
   }
+  if constexpr (SK) {
+    if (sk->mode == 1) { sk_publish(*sk, acc, tid); return; }
+    if (sk->mode == 2) sk_gather(*sk, acc, tid);
+    gemm_epilogue_lds<EPI>(p, acc, a0 + wa * 128, b0 + wb * 64, lane, smem + wid * 16384);     // (the host plans stream-K only for NA % 8 == 0)
+    return;
+  }
   if (OUT_AB || (p.NA & 7) != 0) {
-    gemm_epilogue<EPI, OUT_AB, 4, 2>(p, acc, a0 + wa * 128, b0 + wb * 64, lane, S > 1);
+    gemm_epilogue<EPI, OUT_AB, 4, 2>(p, acc, a0 + wa * 128, b0 + wb * 64, lane, partial);
   } else {
     gemm_epilogue_lds<EPI>(p, acc, a0 + wa * 128, b0 + wb * 64, lane, smem + wid * 16384);
   }
@@ -931,7 +1010,63 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const GemmParams p) {
   } else {
     t = xcd_remap(blockIdx.x, nt); kz = 0;
   }
-  gemm256p_body<A_KS, B_KS, EPI, OUT_AB>(p, t, kz, (int)gridDim.z, smem);
+  int kt0, kt1;
+  split_range(p, kz, (int)gridDim.z, kt0, kt1);
+  gemm256p_body<A_KS, B_KS, EPI, OUT_AB>(p, t, kt0, kt1, gridDim.z > 1, smem);
+}
+
+// ---- stream-K over the partial last round (forward / dgrad kinds: one output tile per workgroup, fused epilogue) ----------------
+// nt tiles on G CUs run as ceil(nt / G) rounds; with nt = 2.52 G (a 1024-column Linear over the 40 992 token rows of 32 volumes: the
+// per-rank shape of an 8-GPU step) the third round is half empty and the GEMM takes 3 tile times for 2.52 tiles' worth of work.
+// Here the first G workgroups share the k-tiles of the LAST sk_tiles tiles EVENLY (workgroup i: iterations W i / G .. W (i + 1) / G of
+// the W = sk_tiles x ktiles of that region, in tile-major order), the other nt - sk_tiles tiles follow one per workgroup as before, and
+// every CU is busy for nt / G tile times (+ the hand-off).  A workgroup's span is cut at tile borders into segments (SkSeg); it
+// computes the segment that does NOT start a tile first and publishes it at once, so by the time an owner reaches its gather the
+// peers' partials have been waiting for a while.  No deadlock for any dispatch order that starts lower block ids first: a peer's
+// segment never waits, and the G stream-K workgroups are the first G blocks of the grid.
+struct SkLaunch {
+  int G, sk_tiles, nt_dp;
+  float* slots;
+  unsigned* flags;
+  unsigned gen;
+};
+template <bool A_KS, bool B_KS, int EPI>
+__global__ __launch_bounds__(512, 1) void gemm256p_sk_kernel(const GemmParams p, const SkLaunch s) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // ONE instance of the tile body serves both kinds of workgroup (two inlined copies of it do not fit the register budget): a
+  // workgroup of the full rounds is a span of exactly one whole tile
+  int i, it, e1, tbase;
+  const long long W = (long long)s.sk_tiles * p.ktiles;
+  if ((int)blockIdx.x >= s.G) {                                   // the full rounds: one tile per workgroup
+    tbase = xcd_remap((int)blockIdx.x - s.G, s.nt_dp);
+    i = s.G; it = 0; e1 = p.ktiles;
+  } else {
+    i = xcd_remap((int)blockIdx.x, s.G);                          // neighbours in the iteration space share an XCD (and its L2)
+    tbase = s.nt_dp;
+    e1 = (int)(W * (i + 1) / s.G);
+    it = (int)(W * i / s.G);
+  }
+  while (it < e1) {
+    const int T = it / p.ktiles, k0 = it - T * p.ktiles;
+    const int tile_end = (T + 1) * p.ktiles;
+    const int k1 = (e1 < tile_end ? e1 : tile_end) - T * p.ktiles;
+    SkSeg sk;
+    sk.slots = s.slots; sk.flags = s.flags; sk.gen = s.gen; sk.slot = i; sk.peer0 = i + 1; sk.npeers = 0;
+    if (k0 > 0) {
+      sk.mode = 1;
+    } else if (k1 < p.ktiles) {
+      sk.mode = 2;
+      int j = i + 1;
+      while (j < s.G && (int)(W * j / s.G) < tile_end) ++j;       // every later workgroup whose span starts inside this tile
+      sk.npeers = j - (i + 1);
+    } else {
+      sk.mode = 0;
+    }
+    gemm256p_body<A_KS, B_KS, EPI, false, true>(p, tbase + T, k0, k1, false, smem, &sk);
+    it = T * p.ktiles + k1;
+    __builtin_amdgcn_s_waitcnt(0xC07F);                           // lgkmcnt(0): the epilogue's LDS reads
+    __syncthreads();                                              // the next segment's LDS-DMA lands in every wave's epilogue region
+  }
 }
 
 // Two weight gradients with the same reduction length (the same token rows) in ONE launch: the tiles of both share the split, so the
@@ -949,8 +1084,14 @@ __global__ __launch_bounds__(512, 1) void gemm256p_wgrad_pair_kernel(const GemmP
   int t = L - kz * nt;
   const bool second = t >= pp.nt0;                              // workgroup-uniform
   if (second) t -= pp.nt0;
-  if (!second) gemm256p_body<true, true, EPI_ACCUM, true>(pp.p0, t, kz, pp.S, smem);
-  else gemm256p_body<true, true, EPI_ACCUM, true>(pp.p1, t, kz, pp.S, smem);
+  int kt0, kt1;
+  if (!second) {
+    split_range(pp.p0, kz, pp.S, kt0, kt1);
+    gemm256p_body<true, true, EPI_ACCUM, true>(pp.p0, t, kt0, kt1, pp.S > 1, smem);
+  } else {
+    split_range(pp.p1, kz, pp.S, kt0, kt1);
+    gemm256p_body<true, true, EPI_ACCUM, true>(pp.p1, t, kt0, kt1, pp.S > 1, smem);
+  }
 }
 
 
@@ -1156,8 +1297,83 @@ std::atomic<int> g_gemm_mfma16{0};
 // and for every shape at 128 volumes -- their workgroups do not end together anyway.
 std::atomic<int> g_wgrad_stagger{29};
 
+// ---- stream-K planning (host) ----------------------------------------------------------------------------------------------
+// Workspace layout: [G slots x 256 KiB fp32 partial tiles][G flags (u32)], G = the device's CU count, caller-owned, lent per call;
+// the flags must have been zero when the workspace was first used (they hold launch generations afterwards and are never reset).
+std::atomic<unsigned> g_sk_gen{1};
+std::atomic<int> g_streamk{1};       // octmae_set_option("gemm_streamk", 0 / 1); OCTMAE_STREAMK overrides
+std::atomic<int> g_sk_launches{0};   // how many launches took the stream-K kernel (octmae_set_option("gemm_streamk_launches", any): tests)
+static int device_cus() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int v = cached[dev & 63].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+  cached[dev & 63].store(v, std::memory_order_relaxed);
+  return v;
+}
+static long long sk_ws_bytes_for(int G) { return (long long)G * SK_SLOT_FLOATS * 4 + (long long)G * 4; }
+// How many of the LAST tiles of an nt-tile launch go to the stream-K workgroups (0: none -- plain launch).  Taken when the last round
+// of workgroups would be between an eighth and 80 % full (a fuller one gains less than the hand-off costs; an emptier one is mostly
+// hidden already: the workgroups of a round end 40-70 us apart and the stragglers' CUs take the few extra tiles), or when the whole
+// launch has fewer tiles than CUs (small batches) and every workgroup still gets >= 4 k-tiles.
+static int sk_plan(int nt, int ktiles, int G, int* G_eff) {
+  static const int env = getenv("OCTMAE_STREAMK") ? atoi(getenv("OCTMAE_STREAMK")) : -1;
+  const int on = env >= 0 ? env : g_streamk.load(std::memory_order_relaxed);
+  *G_eff = G;
+  if (!on || ktiles < 4) return 0;
+  if (nt >= G) {
+    const int rem = nt % G;
+    // every stream-K workgroup gets >= 4 k-tiles (an empty span would publish nothing and its owner would wait for ever)
+    long long g = (long long)rem * ktiles / 4;
+    if (g > G) g = G;
+    *G_eff = (int)g;
+    if (g < 2LL * rem) return 0;                           // would not even double the fill of that round
+    if (on == 2) return rem;                               // 2: whenever there is a partial round (measurement)
+    return (rem * 8 >= G && rem * 10 <= G * 8) ? rem : 0;
+  }
+  // fewer tiles than CUs: all of them, over as many workgroups as leave each >= 4 k-tiles -- only if that at least doubles the fill
+  long long g = (long long)nt * ktiles / 4;
+  if (g > G) g = G;
+  if (g < 2LL * nt) return 0;
+  *G_eff = (int)g;
+  return nt;
+}
+
+template <bool A_KS, bool B_KS, int EPI>
+static int launch256_sk(const GemmParams& p, hipStream_t st, void* ws, long long ws_bytes, bool* taken) {
+  *taken = false;
+  const int nt = p.tiles_a * p.tiles_b, G = device_cus();
+  int Ge = G;
+  const int skt = (ws && ws_bytes >= sk_ws_bytes_for(G) && (p.NA & 7) == 0) ? sk_plan(nt, p.ktiles, G, &Ge) : 0;
+  if (skt <= 0) return 0;
+  SkLaunch s;
+  s.G = Ge; s.sk_tiles = skt; s.nt_dp = nt - skt;
+  s.slots = reinterpret_cast<float*>(ws);
+  s.flags = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + (long long)G * SK_SLOT_FLOATS * 4);
+  s.gen = g_sk_gen.fetch_add(1, std::memory_order_relaxed);
+  if (s.gen == 0) s.gen = g_sk_gen.fetch_add(1, std::memory_order_relaxed);     // 0 is the initial content of the flags
+  auto kern = gemm256p_sk_kernel<A_KS, B_KS, EPI>;
+  static DynLdsOnce once;
+  if (int rc = once.ensure(reinterpret_cast<const void*>(kern), 4 * TILE2_BYTES)) return rc;
+  hipLaunchKernelGGL(kern, dim3(Ge + s.nt_dp, 1, 1), dim3(512), 4 * TILE2_BYTES, st, p, s);
+  OCTMAE_LAUNCH_CHECK();
+  *taken = true;
+  g_sk_launches.fetch_add(1, std::memory_order_relaxed);
+  return 0;
+}
+
 template <bool A_KS, bool B_KS, int EPI, bool OUT_AB>
-static int launch256(const GemmParams& p, int splitk, hipStream_t st, bool phased, bool mfma16) {
+static int launch256(const GemmParams& p, int splitk, hipStream_t st, bool phased, bool mfma16, void* sk_ws = nullptr,
+                     long long sk_bytes = 0) {
+  if constexpr (!OUT_AB && !(A_KS && B_KS)) {
+    if (phased && !mfma16 && splitk == 1 && sk_ws != nullptr) {
+      bool taken = false;
+      if (int rc = launch256_sk<A_KS, B_KS, EPI>(p, st, sk_ws, sk_bytes, &taken)) return rc;
+      if (taken) return 0;
+    }
+  }
   if constexpr (!OUT_AB && !(A_KS && B_KS)) {
     if (mfma16 && phased && splitk == 1 && (p.NA & 7) == 0) {
       auto kq = gemm256q_kernel<A_KS, B_KS, EPI>;
@@ -1211,7 +1427,7 @@ extern "C" int octmae_colsum_accum(const void* in, int in_is_bf16, float* out, i
 static int gemm_impl(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
                      int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided,
                      int b_kstrided, int epilogue, int splitk, void* stream, const float* rowscale, int rows_per_scale,
-                     float* colsum_ws = nullptr) {
+                     float* colsum_ws = nullptr, void* sk_ws = nullptr, long long sk_bytes = 0) {
   // bit 8 of `epilogue` forces the 128-tile kernel, bit 9 the two-stage (un-phased) 256-tile main loop: tests and A/B runs
   // exercise every kernel on the same problem
   const int variant = (epilogue >> 8) & 1;
@@ -1288,7 +1504,7 @@ static int gemm_impl(const void* A, const void* B, void* C, void* C2, const floa
   if (epilogue == EPI_DGELU && p.C2 != nullptr && colsum_ws != nullptr) { p.C2 = colsum_ws; p.ldc2 = NA; }
 #define OCTMAE_GEMM_CASE(AKS, BKS, E, AB)                                  \
   if (a_kstrided == AKS && b_kstrided == BKS && epilogue == E) {           \
-    int rc_ = big ? launch256<AKS, BKS, E, AB>(p, splitk, st, phased, mfma16) : launch<AKS, BKS, E, AB>(p, splitk, st);  \
+    int rc_ = big ? launch256<AKS, BKS, E, AB>(p, splitk, st, phased, mfma16, sk_ws, sk_bytes) : launch<AKS, BKS, E, AB>(p, splitk, st);  \
     if (rc_ == 0 && E == EPI_DGELU && dgelu_colsum != nullptr && p.C2 == nullptr)                                       \
       rc_ = octmae_colsum_accum(C, 1, dgelu_colsum, NB, NA, ldc, stream);                                                \
     if (rc_ == 0 && E == EPI_DGELU && dgelu_colsum != nullptr && p.ldc2 > 0)                                             \
@@ -1390,19 +1606,29 @@ extern "C" int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2,
                    nullptr, 1);
 }
 
+extern "C" int octmae_gemm_streamk_ws_kib(void) { return (int)((sk_ws_bytes_for(device_cus()) + 1023) / 1024); }
+
+extern "C" int octmae_gemm_bf16_ws(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
+                                   int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided,
+                                   int b_kstrided, int epilogue, int splitk, void* sk_ws, long long sk_ws_bytes, void* stream) {
+  return gemm_impl(A, B, C, C2, bias, aux, NA, NB, K, lda, ldb, ldc, ldaux, a_kstrided, b_kstrided, epilogue, splitk, stream,
+                   nullptr, 1, nullptr, sk_ws, sk_ws_bytes);
+}
+
 extern "C" int octmae_linear_resid_rowscale(const void* W, const void* X, float* out, const float* bias, const float* res,
                                             const float* rowscale, int rows_per_scale, int N, int M, int K, int ldw, int ldx,
-                                            int ldout, int ldres, int small_tile, void* stream) {
+                                            int ldout, int ldres, int small_tile, void* sk_ws, long long sk_ws_bytes, void* stream) {
   OCTMAE_CHECK_ARG(rowscale != nullptr && rows_per_scale > 0);
   return gemm_impl(W, X, out, nullptr, bias, res, N, M, K, ldw, ldx, ldout, ldres, 0, 0, EPI_RESID | (small_tile & 0xF00), 1,
-                   stream, rowscale, rows_per_scale);
+                   stream, rowscale, rows_per_scale, nullptr, sk_ws, sk_ws_bytes);
 }
 
 // dX[M][K] bf16 = dY[M][N] @ W[N][K]  and  delta[M][H] f32 = -sum over each head's hd columns of dX * O  (O bf16 [M][K], K = H * hd):
 // the proj dgrad of an attention block, whose output dO the attention backward multiplies with O row by row anyway.
 // Returns -2 when the problem does not take the 256-tile kernel (the caller then uses octmae_gemm_bf16 + octmae_attn_bwd_fused).
 extern "C" int octmae_linear_dgrad_delta(const void* W, const void* dY, void* dX, const void* O, float* delta, int M, int N, int K,
-                                         int ldw, int ldy, int ldx, int ldo, int H, int hd, int variant, void* stream) {
+                                         int ldw, int ldy, int ldx, int ldo, int H, int hd, int variant, void* sk_ws,
+                                         long long sk_ws_bytes, void* stream) {
   OCTMAE_CHECK_ARG(W && dY && dX && O && delta && M > 0 && N > 0 && K > 0);
   OCTMAE_CHECK_ARG((hd == 32 || hd == 64) && H > 0 && H * hd == K && (ldw % 8) == 0 && (ldy % 8) == 0 && (ldx % 4) == 0 && (ldo % 4) == 0);
   OCTMAE_CHECK_ARG(K % 8 == 0 && N % 8 == 0);
@@ -1419,9 +1645,14 @@ extern "C" int octmae_linear_dgrad_delta(const void* W, const void* dY, void* dX
   p.cgroup = p.tiles_a;
   if (p.tiles_a >= 16 && p.tiles_a % 4 == 0 && 4 * (size_t)T2 * N * 2 <= (2u << 20)) p.cgroup = 4;
   p.hd = hd; p.ldc2 = H; p.kstagger = 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (sk_ws != nullptr) {
+    bool taken = false;
+    if (int rc = launch256_sk<true, false, EPI_DELTA>(p, st, sk_ws, sk_ws_bytes, &taken)) return rc;
+    if (taken) return 0;
+  }
   auto kern = gemm256p_kernel<true, false, EPI_DELTA, false>;
   static DynLdsOnce once;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (int rc = once.ensure(reinterpret_cast<const void*>(kern), 4 * TILE2_BYTES)) return rc;
   hipLaunchKernelGGL(kern, dim3(p.tiles_a * p.tiles_b, 1, 1), dim3(512), 4 * TILE2_BYTES, st, p);
   OCTMAE_LAUNCH_CHECK();
@@ -1431,8 +1662,9 @@ extern "C" int octmae_linear_dgrad_delta(const void* W, const void* dY, void* dX
 extern "C" int octmae_dgelu_colsum_ws_rows(int M) { return M > 0 ? 4 * ((M + T2 - 1) / T2) : 0; }
 
 extern "C" int octmae_linear_dgrad_dgelu(const void* W, const void* dY, void* dX, const void* pre, float* ws, float* bias_grad,
-                                         int M, int N, int K, int ldw, int ldy, int ldx, int ldpre, int small_tile, void* stream) {
+                                         int M, int N, int K, int ldw, int ldy, int ldx, int ldpre, int small_tile, void* sk_ws,
+                                         long long sk_ws_bytes, void* stream) {
   OCTMAE_CHECK_ARG(bias_grad == nullptr || ws != nullptr);
   return gemm_impl(W, dY, dX, bias_grad, nullptr, pre, K, M, N, ldw, ldy, ldx, ldpre, 1, 0, EPI_DGELU | (small_tile & 0xF00), 1, stream, nullptr, 1,
-                   bias_grad != nullptr ? ws : nullptr);
+                   bias_grad != nullptr ? ws : nullptr, sk_ws, sk_ws_bytes);
 }

@@ -196,11 +196,43 @@ def _variant_bits():
         (0x800 if FORCE_MFMA32 else 0)
 
 
+# Stream-K workspace of the forward / dgrad GEMMs (octmae_gemm_bf16_ws): one per (device, stream) -- launches on one stream run one
+# after the other and may share it, launches on different streams may not.  64 MiB of partial-tile slots + one flag per CU, zeroed
+# once (the flags then hold launch generations).  OFF by default: built, parity-green and race-free (tests/test_gpu_streamk.py), and
+# measured to buy nothing -- the 2.52-round GEMMs of a 32-volume rank already run their half-empty last round 1.6 x faster per
+# tile (the step is power-bound: idle CUs hand their watts to the busy ones), 202.1 vs 202.8 ms per 32-volume step; below one round
+# of tiles the gather of many 256 KiB partials by one CU costs more than the idle CUs (profiles/r05_streamk_ab.txt, DESIGN.md
+# section 4).  bench.py --set ops.STREAMK=1 / OCTMAE_STREAMK_WS=1 lends the workspace.
+STREAMK = os.environ.get("OCTMAE_STREAMK_WS", "0") == "1"
+_sk_ws = {}
+
+
+def _streamk_ws(st: int):
+    """(pointer, bytes) of the current device's workspace for stream handle `st`, or (None, 0)."""
+    if not STREAMK:
+        return None, 0
+    key = (torch.cuda.current_device(), st)
+    ws = _sk_ws.get(key)
+    if ws is None:
+        if len(_sk_ws) >= 8:                        # a process that keeps creating streams: do not hoard 64 MiB for each
+            _sk_ws.clear()
+        ws = _sk_ws[key] = torch.zeros(load().octmae_gemm_streamk_ws_kib() * 1024, dtype=torch.uint8, device="cuda")
+    return ws.data_ptr(), ws.numel()
+
+
 def _gemm(A, B, C, NA, NB, K, lda, ldb, ldc, a_ks, b_ks, epi, C2=None, bias=None, aux=None, ldaux=0, splitk=1):
-    args = (A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(C2), _p(bias), _p(aux), NA, NB, K, lda, ldb, ldc, ldaux, a_ks, b_ks,
-            epi | _variant_bits(), splitk, _stream())
+    st = _stream()
+    if epi != EPI_ACCUM and not FORCE_SMALL_TILE:   # forward / dgrad kinds: lend the stream-K workspace
+        skp, skn = _streamk_ws(st)
+        args = (A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(C2), _p(bias), _p(aux), NA, NB, K, lda, ldb, ldc, ldaux, a_ks, b_ks,
+                epi | _variant_bits(), splitk, skp, skn, st)
+        fn = "octmae_gemm_bf16_ws"
+    else:
+        args = (A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(C2), _p(bias), _p(aux), NA, NB, K, lda, ldb, ldc, ldaux, a_ks, b_ks,
+                epi | _variant_bits(), splitk, st)
+        fn = "octmae_gemm_bf16"
     if KTIMER is None:
-        call("octmae_gemm_bf16", *args)
+        call(fn, *args)
     else:
         kind = f"{_GEMM_KIND.get((a_ks, b_ks), 'gemm')}_epi{epi}"
         # algorithmic bytes: both operands once, the output, the second output of the GELU epilogue (2), the residual (3) or
@@ -210,7 +242,7 @@ def _gemm(A, B, C, NA, NB, K, lda, ldb, ldc, a_ks, b_ks, epi, C2=None, bias=None
             nbytes += C2.element_size() * NA * NB
         if epi in (3, 4) and aux is not None:
             nbytes += aux.element_size() * NA * NB
-        KTIMER.launch(kind, 2.0 * NA * NB * K, nbytes, lambda: call("octmae_gemm_bf16", *args))
+        KTIMER.launch(kind, 2.0 * NA * NB * K, nbytes, lambda: call(fn, *args))
 
 
 def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mode: str = "bf16",
@@ -223,8 +255,9 @@ def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], m
     if rowscale is not None:
         assert mode == "resid" and rowscale.dtype == F32 and rowscale.numel() * rows_per_scale == M
         out = torch.empty((M, N), dtype=F32, device=dev)
+        st = _stream()
         args = (w.data_ptr(), x.data_ptr(), out.data_ptr(), _p(bias), res.data_ptr(), rowscale.data_ptr(), rows_per_scale, N, M, K,
-                w.stride(0), x.stride(0), N, res.stride(0), _variant_bits(), _stream())
+                w.stride(0), x.stride(0), N, res.stride(0), _variant_bits(), *_streamk_ws(st), st)
         _launch(f"gemm_fwd_epi{EPI_RESID}", 2.0 * N * M * K, 2.0 * (N * K + M * K) + 8.0 * N * M,
                 lambda: call("octmae_linear_resid_rowscale", *args))
         return out
@@ -265,8 +298,9 @@ def linear_dgrad(dy: torch.Tensor, w: torch.Tensor, pre: Optional[torch.Tensor] 
     else:
         rows = load().octmae_dgelu_colsum_ws_rows(M)
         ws = torch.empty((rows, K), dtype=F32, device=dy.device)
+        st = _stream()
         args = (w.data_ptr(), dy.data_ptr(), dx.data_ptr(), pre.data_ptr(), ws.data_ptr(), colsum.data_ptr(), M, N, K, w.stride(0),
-                dy.stride(0), K, pre.stride(0), _variant_bits(), _stream())
+                dy.stride(0), K, pre.stride(0), _variant_bits(), *_streamk_ws(st), st)
         if KTIMER is None:
             call("octmae_linear_dgrad_dgelu", *args)
         else:   # two launches (GEMM + the fold of the partial sums), timed together
@@ -289,8 +323,9 @@ def linear_dgrad_delta(dy: torch.Tensor, w: torch.Tensor, o: torch.Tensor, H: in
         return linear_dgrad(dy, w), None
     dx = torch.empty((M, K), dtype=BF16, device=dy.device)
     delta = torch.empty((M, H), dtype=F32, device=dy.device)
+    st = _stream()
     args = (w.data_ptr(), dy.data_ptr(), dx.data_ptr(), o.data_ptr(), delta.data_ptr(), M, N, K, w.stride(0), dy.stride(0), K, o.stride(0),
-            H, HD, _variant_bits(), _stream())
+            H, HD, _variant_bits(), *_streamk_ws(st), st)
     rc = [0]
 
     def run():
