@@ -226,6 +226,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.gloo_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("OCTMAE_BENCH_FORCE_LOCAL_RANK") is not None:      # tests: several ranks on one GPU with the NATIVE backend selected
+        local_rank = int(os.environ["OCTMAE_BENCH_FORCE_LOCAL_RANK"])
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
@@ -263,12 +265,46 @@ def main():
         elif args.torch_nccl:
             comm_kind = "torch.distributed nccl (--torch-nccl)"
         else:
+            # EVERY rank leaves with status 3 when ANY rank cannot create the communicator: ncclCommInitRank is collective, so the
+            # peers of a rank whose creation failed would otherwise sit in it for ever.  The failing rank publishes a key in the
+            # control-plane store; a watchdog thread on every rank polls that key while the rank itself may be blocked inside the
+            # creation, and ends the process (os._exit: nothing in this process can be unwound out of a blocked RCCL call).
+            import threading
+            store = dist.distributed_c10d._get_default_store()
+            fail_key, done = "octmae/bench/comm_failed", threading.Event()
+
+            def _watch():
+                while not done.wait(0.5):
+                    try:
+                        failed = store.check([fail_key])
+                    except Exception:
+                        return
+                    if failed:
+                        print(f"[bench] rank {rank}: a peer could not create the native RCCL communicator: exiting with status 3",
+                              file=sys.stderr, flush=True)
+                        os._exit(3)
+            threading.Thread(target=_watch, daemon=True).start()
             try:
-                comm = ocomm.NativeComm.from_store(dist.distributed_c10d._get_default_store(), rank, world, local_rank)
+                if os.environ.get("OCTMAE_BENCH_FAIL_COMM_RANK") == str(rank):      # tests: this rank's creation fails
+                    raise RuntimeError("simulated communicator failure (OCTMAE_BENCH_FAIL_COMM_RANK)")
+                comm = ocomm.NativeComm.from_store(store, rank, world, local_rank)
             except Exception as e:
                 print(f"[bench] rank {rank}: FATAL: the native RCCL communicator (octmae_comm_*) could not be created: {e!r}.  "
                       "Pass --torch-nccl to measure torch.distributed's NCCL group instead.", file=sys.stderr, flush=True)
+                try:
+                    store.set(fail_key, str(rank))
+                except Exception:
+                    pass
                 sys.exit(3)
+            # every rank is through: count them in before the watchdog stands down (a peer may still fail after this rank succeeded)
+            store.add("octmae/bench/comm_ok", 1)
+            t_end = time.time() + 300
+            while int(store.add("octmae/bench/comm_ok", 0)) < world and not store.check([fail_key]) and time.time() < t_end:
+                time.sleep(0.05)
+            if store.check([fail_key]) or int(store.add("octmae/bench/comm_ok", 0)) < world:
+                print(f"[bench] rank {rank}: not every rank created its communicator: exiting with status 3", file=sys.stderr, flush=True)
+                os._exit(3)
+            done.set()
             ocomm.set_default(comm)
             comm_kind = "octmae_comm (RCCL behind the C ABI)"
 

@@ -150,7 +150,10 @@ class FlatGradReducer:
         self._in_backward = True
         self._reports = {}
         self._order_now = []
-        self._overlap_now = self._sync and self.overlap and not (self.multi_use and self._expected is None)
+        # The LEARNING step (layout not frozen yet) launches nothing during backward: its chunks go out in finish(), in index order --
+        # the same order on every rank whatever order their gradients arrived in.  (Until round 4 it launched by readiness and the
+        # order was only compared afterwards: a rank that diverged in that one step could hang its peers before the check ran.)
+        self._overlap_now = self._sync and self.overlap and self._frozen and not (self.multi_use and self._expected is None)
         self._tl = None
         if self.timing and self._sync:
             self._tl = {"b0": self._event_now(), "chunks": [], "host_wait_ms": 0.0}
@@ -244,6 +247,9 @@ class FlatGradReducer:
             i = len(self._order_now)
             if i >= len(self._order_learned) or self._order_learned[i] != c:
                 exp = self._order_learned[i] if i < len(self._order_learned) else None
+                # This rank stops BEFORE it enqueues the mismatched collective.  Its peers have enqueued theirs and wait for it: they
+                # end through the collective timeout of their transport (gloo: the group's timeout; RCCL: NCCL_TIMEOUT / the
+                # launcher's watchdog) -- torchrun then tears the job down because this rank exited with an error.
                 raise RuntimeError(f"FlatGradReducer: gradient chunk {c} became ready as launch #{i} of this backward, but the order "
                                    f"agreed across ranks has chunk {exp} there -- this rank's control flow diverged from the step the "
                                    "schedule was learned from (collectives are matched by sequence: exchanging now would hang or "

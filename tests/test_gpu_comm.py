@@ -51,6 +51,15 @@ if os.environ.get("OCTMAE_SKIP_BENCH4_TEST") is None and torch.cuda.device_count
          "--global-batch", "16", "--micro-batch", "4", "--steps", "2", "--warmup", "2"],
         cwd=ROOT, env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
 
+# ---- 2 ranks, native backend, rank 1 fails to create its communicator: every rank must leave with status 3 -------------------------
+_CHILD_FAIL = None
+if os.environ.get("OCTMAE_SKIP_COMM_FAIL_TEST") is None and torch.cuda.device_count() >= 1:
+    _CHILD_FAIL = subprocess.Popen(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", "29627", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+        cwd=ROOT, env=dict(os.environ, OCTMAE_BENCH_FORCE_LOCAL_RANK="0", OCTMAE_BENCH_FAIL_COMM_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0"),
+        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
 if torch.cuda.is_available():
     from octcubem_amd import comm as ocomm, models_mae, misc, optim as foptim
     from octcubem_amd.parallel import FlatGradReducer
@@ -238,3 +247,20 @@ def test_bench_script_with_four_ranks_prints_one_line_and_ranks_agree():
     red = c["reducer"]
     assert red["transport"] == "torch.distributed/gloo" and red["launched_in_backward"] > 0
     assert any(red["cold_chunk"])                                  # high_res_patch_embed: exchanged at begin_backward()
+
+
+def test_every_rank_exits_3_when_one_rank_cannot_create_the_communicator():
+    """bench.py --gpus 2 with the native backend: rank 1's communicator creation fails (simulated), rank 0 is then blocked inside the
+    collective ncclCommInitRank waiting for it -- its watchdog thread must see the failure key in the control-plane store and end the
+    process with status 3 (only the failing rank used to exit)."""
+    if _CHILD_FAIL is None:
+        pytest.skip("no GPU at collection time")
+    try:
+        out, err = _CHILD_FAIL.communicate(timeout=240)
+    except subprocess.TimeoutExpired:
+        _CHILD_FAIL.kill()
+        raise AssertionError("the ranks did not end: a rank is still blocked in the communicator creation")
+    text = err.decode(errors="replace")
+    assert _CHILD_FAIL.returncode != 0
+    assert "simulated communicator failure" in text
+    assert "a peer could not create the native RCCL communicator" in text or "not every rank created its communicator" in text, text[-3000:]
