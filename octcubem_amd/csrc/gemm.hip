@@ -1285,7 +1285,7 @@ __global__ __launch_bounds__(512, 1) void gemm256q_kernel(const GemmParams p) {
 
 // 16x16x32 MFMAs in the 256-tile forward / dgrad kernels (octmae_set_option "gemm_mfma16"; bit 11 of the epilogue argument forces
 // the 32x32x16 kernel for tests and A/B runs)
-// Default OFF: same-process A/B of the kernels alone (tools/gemm_mfma_shape_ab.py) has the 16x16x32 form 2-5 % faster on every
+// Default OFF: same-process A/B of the kernels alone (tools/archive/gemm_mfma_shape_ab.py) has the 16x16x32 form 2-5 % faster on every
 // shape, but in the training step on the same box (bench.py --set gemm_mfma16=1 vs 0, three alternations) it is no faster
 // (167.5 vs 167.7 volumes/s; dgrad +3.7 % slower, forward -1 %): profiles/r04_gemm_mfma16_ab.txt.
 std::atomic<int> g_gemm_mfma16{0};
@@ -1293,7 +1293,7 @@ std::atomic<int> g_gemm_mfma16{0};
 // 1/256 k-tiles PER OUTPUT TILE of the launch (the atomic time of a slice grows with its tile count: 256 KiB at 1.35 TB/s = 0.19 us
 // per tile against 1.7 us per k-tile, i.e. v = 29); 0 = equal slices.  octmae_set_option("wgrad_stagger", v) / OCTMAE_WGRAD_STAGGER.
 // Applied only to splits of >= 8 slices with <= 96 k-tiles each (the [C x C] proj gradients at <= 32 volumes per rank): measured
-// (tools/wgrad_stagger_ab.py, profiles/r04_wgrad_stagger.txt) -9 / -11 % there, and nothing or a loss for the 4- and 5-way splits
+// (tools/archive/wgrad_stagger_ab.py, profiles/r04_wgrad_stagger.txt) -9 / -11 % there, and nothing or a loss for the 4- and 5-way splits
 // and for every shape at 128 volumes -- their workgroups do not end together anyway.
 std::atomic<int> g_wgrad_stagger{29};
 

@@ -367,7 +367,7 @@ WGRAD_PAIR = os.environ.get("OCTMAE_WGRAD_PAIR", "1") != "0"
 def linear_wgrad_accum_pair(first, second):
     """Two linear_wgrad_accum calls over the same token rows -- (dy, x, gw, gb) each -- as ONE launch: the tiles of both outputs
     share the split over the rows, so there are half as many fp32-atomic epilogues and the k-loops are twice as long (measured on
-    the combined shape, tools/wgrad_group_bound.py: -12 ... -15 % at 32 volumes, -2 ... -7 % at 128).  Falls back to two launches when
+    the combined shape, tools/archive/wgrad_group_bound.py: -12 ... -15 % at 32 volumes, -2 ... -7 % at 128).  Falls back to two launches when
     the library says the pair does not apply (-2) or WGRAD_PAIR is off."""
     (dy0, x0, gw0, gb0), (dy1, x1, gw1, gb1) = first, second
     M = dy0.shape[0]
@@ -443,7 +443,7 @@ def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, HD: int, scale: float, o
 
 
 # Which backward runs per head_dim: the single-pass kernel (csrc/attn_bwd.hip) or the dQ + dK/dV kernel pair (csrc/attn.hip).
-# Measured on MI355X (tools/attn_bwd_ab.py, same process, interleaved): head_dim 32 (decoder, N = 5121) fused 11 % faster;
+# Measured on MI355X (tools/archive/attn_bwd_ab.py, same process, interleaved): head_dim 32 (decoder, N = 5121) fused 11 % faster;
 # head_dim 64 fused 4 % faster at N = 1281 (encoder) and 2 % at N = 5121 (fine-tune) since its LDS-DMA requests go out between
 # the sub-tiles and its sub-tile addressing is hand-placed (before: the pair 10-13 % faster).
 ATTN_BWD_FUSED = {32: True, 64: True}
