@@ -397,3 +397,5 @@ class FlatGradReducer:
                 self.comm.wait()
             else:
                 dist.broadcast(self._arena.flat, src=src, group=self.group)
+            # the arena was written as ONE tensor: no parameter's version counter moved, so say it (the next forward re-casts)
+            self._arena.invalidate_lp()
