@@ -275,7 +275,53 @@ def case_vit_st_l(out):
     out["vit_st_l/loss_scale"] = S
 
 
-CASES = {"small": case_small, "mid": case_mid, "mae2d_small": case_mae2d, "vit_st_small": case_vit_st, "vitl": case_vitl,
+def case_train(out):
+    """Two optimizer steps through the reference-shaped loop -- NativeScalerWithGradNormCount + FusedAdamW + lr schedule -- against the
+    oracle's forward / backward + AdamW, each step from the HIP model's own parameters.  On the half build the scaler runs the
+    reference's GradScaler state machine (dynamic_loss_scale=True, initial scale 65536: custom_util/misc.py:311-344); on bfloat16 it is
+    the identity.  Entries: loss, gradient norm as the scaler returns it (un-scaled), 1 - cos(update direction) of the two steps."""
+    import tests.test_gpu_model as TM
+    from octcubem_amd import misc, lr_sched, optim as foptim
+    from oracle import mae3d_ref as O
+    cfg = O.MAEConfig(input_size=64, in_chans=1, embed_dim=128, depth=2, num_heads=2, decoder_embed_dim=64, decoder_depth=1,
+                      decoder_num_heads=2, num_frames=6, t_patch_size=3, pred_t_dim=6, high_res_input_size=128)
+    P = O.init_params(cfg, seed=5, bias_std=0.02)
+    m = TM.build(cfg, P)
+    opt = foptim.FusedAdamW(misc.add_weight_decay(m, 0.05), lr=1e-3, betas=(0.9, 0.95))
+    scaler = misc.NativeScalerWithGradNormCount(dynamic_loss_scale=ops.LP_IS_F16)
+
+    class A: pass
+    a = A(); a.lr = 1e-3; a.min_lr = 0.0; a.warmup_epochs = 1; a.epochs = 10
+    nd, _ = O.weight_decay_groups([(k, tuple(v.shape)) for k, v in P.items()], 0.05)
+    nd = set(nd)
+    Mr = {k: torch.zeros_like(v) for k, v in P.items()}; Vr = {k: torch.zeros_like(v) for k, v in P.items()}
+    dot = n1 = n2 = 0.0
+    for step in (1, 2):
+        imgs = torch.rand(2, 1, 6, 64, 64, generator=torch.Generator().manual_seed(10 + step))
+        noise = torch.rand(2, cfg.num_patches, generator=torch.Generator().manual_seed(20 + step))
+        lr = lr_sched.adjust_learning_rate(opt, 0.5 * step, a)
+        before = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        opt.zero_grad()
+        loss, _, _ = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
+        norm = scaler(loss, opt, parameters=m.parameters(), clip_grad=None)
+        assert not scaler.last_step_skipped, "the dynamic loss scale skipped a step at its initial scale"
+        loss_r, _, _, _, G = O.forward_backward(before, imgs, cfg, 0.75, noise)
+        out[f"train/loss{step}"] = abs(float(loss) - float(loss_r)) / float(loss_r)
+        gn = float(O.grad_norm(G.values()))
+        out[f"train/grad_norm{step}"] = abs(float(norm) - gn) / gn
+        after = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        for k in before:
+            pr, Mr[k], Vr[k] = O.adamw_step(before[k], G[k], Mr[k], Vr[k], step, lr, 0.9, 0.95, 1e-8, 0.0 if k in nd else 0.05)
+            if float(G[k].norm()) < 1e-3 * gn:
+                continue
+            du, dr = (after[k] - before[k]).double().flatten(), (pr - before[k]).double().flatten()
+            dot += float(du @ dr); n1 += float(du @ du); n2 += float(dr @ dr)
+        # the moments of the comparison follow the HIP model's trajectory from here on (same start for step 2)
+    out["train/1-cos(update)"] = 1.0 - dot / (n1 * n2) ** 0.5
+    out["train/loss_scale"] = float(scaler.get_scale())
+
+
+CASES = {"train": case_train, "small": case_small, "mid": case_mid, "mae2d_small": case_mae2d, "vit_st_small": case_vit_st, "vitl": case_vitl,
          "vit_st_l": case_vit_st_l}
 
 

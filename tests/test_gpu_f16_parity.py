@@ -78,6 +78,21 @@ SINGLE_TENSOR = ("worst_grad", "grad_samples_max", "worst_tensor_norm")
 CASES = ("small", "mid", "mae2d_small", "vit_st_small", "vitl", "vit_st_l")
 
 
+def test_half_build_trains_through_the_dynamic_loss_scale():
+    """The reference-shaped iteration on the half build: NativeScalerWithGradNormCount(dynamic_loss_scale=True) -- the reference's
+    GradScaler (custom_util/misc.py:311-344) -- does not skip a step at its initial scale, returns the UN-scaled gradient norm, and
+    two AdamW steps move the weights where the oracle's AdamW moves them; losses and norms within 1e-3."""
+    from tests.conftest import parity
+    f, b = _ledger("f16")["entries"], _ledger("bf16")["entries"]
+    assert f["train/loss_scale"] == 65536.0 and b["train/loss_scale"] == 1.0
+    for k in ("train/loss1", "train/loss2", "train/grad_norm1", "train/grad_norm2"):
+        parity("f16/" + k, f[k], 1e-3)
+        parity("bf16/" + k, b[k], 3.5e-3)
+    parity("f16/train/1-cos(update)", f["train/1-cos(update)"], 1e-3)
+    parity("bf16/train/1-cos(update)", b["train/1-cos(update)"], 5e-3)
+    assert f["train/1-cos(update)"] <= b["train/1-cos(update)"]
+
+
 def test_half_build_is_the_half_build():
     f = _ledger("f16")
     b = _ledger("bf16")
