@@ -1333,12 +1333,16 @@ static int sk_plan(int nt, int ktiles, int G, int* G_eff) {
     if (on == 2) return rem;                               // 2: whenever there is a partial round (measurement)
     return (rem * 8 >= G && rem * 10 <= G * 8) ? rem : 0;
   }
-  // fewer tiles than CUs: all of them, over as many workgroups as leave each >= 4 k-tiles -- only if that at least doubles the fill
-  long long g = (long long)nt * ktiles / 4;
-  if (g > G) g = G;
-  if (g < 2LL * nt) return 0;
-  *G_eff = (int)g;
-  return nt;
+  // Fewer tiles than CUs (1-4 volumes per step: the reference's shipped recipe runs ONE volume per GPU).  Every launch then costs one
+  // tile time whatever its size; only the longest k-loops are worth splitting: each tile into 4 EQUAL parts of >= 12 k-tiles (one
+  // owner + 3 peers: K >= 3072, i.e. fc2 forward and the fc1 / qkv dgrads of the encoder).  Measured (profiles/r05_streamk_ab.txt):
+  // -9 ... -19 % on those launches at one volume; a 2-way split of K = 2048 loses 20-40 % (publish + gather cost ~15 us, more than
+  // half a k-loop), a 10-way split 40-190 % (one CU gathering ten 256 KiB partials).
+  if (4LL * nt <= G && ktiles / 4 >= 12) {
+    *G_eff = 4 * nt;
+    return nt;
+  }
+  return 0;
 }
 
 template <bool A_KS, bool B_KS, int EPI>

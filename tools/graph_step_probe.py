@@ -1,10 +1,13 @@
 """Probe: capture forward + backward of the ViT-L 3-D MAE step in a HIP graph (torch.cuda.CUDAGraph over the ctypes-launched kernels)
 and replay it: same loss / gradients as the eager step?  how much faster at 1, 2, 4, 8 volumes (the eager step is host-bound there:
 ~240 launches need ~23 ms to enqueue)?   python tools/graph_step_probe.py [batches...]"""
+import faulthandler
 import sys
 import time
 
 import torch
+
+faulthandler.enable()
 
 sys.path.insert(0, ".")
 from octcubem_amd import models_mae, misc, ops, optim as foptim  # noqa: E402
@@ -28,11 +31,7 @@ def eager_fb(x, noise):
 for B in batches:
     x = torch.rand(B, 1, 60, 256, 256, device=dev)
     noise = torch.rand(B, 5120, device=dev)
-    # eager reference (gradients of one forward + backward from zero)
-    opt.zero_grad()
-    l_e = eager_fb(x, noise).detach().clone()
-    g_e = model.arena.grad.clone()
-    # capture
+    # capture FIRST (the AccumulateGrad nodes of the PyTorch-side parameters are then created on the capture stream), eager reference after
     sx, sn = x.clone(), noise.clone()
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
@@ -53,8 +52,13 @@ for B in batches:
     opt.zero_grad()
     g.replay()
     torch.cuda.synchronize()
-    same_loss = torch.equal(sl.detach(), l_e)
-    dg = float((model.arena.grad.double() - g_e.double()).norm() / g_e.double().norm())
+    l_g, g_g = sl.detach().clone(), model.arena.grad.clone()
+    opt.zero_grad()
+    l_e = eager_fb(x, noise).detach().clone()
+    g_e = model.arena.grad.clone()
+    torch.cuda.synchronize()
+    same_loss = torch.equal(l_g, l_e)
+    dg = float((g_g.double() - g_e.double()).norm() / g_e.double().norm())
     # timing: eager step vs replay + eager optimizer
     def step_eager():
         opt.zero_grad()
