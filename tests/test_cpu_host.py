@@ -320,3 +320,38 @@ def test_device_prefetcher_is_a_pass_through_on_the_cpu():
     out = list(pf)
     assert all(a is b for a, b in zip(out, batches))
     assert list(misc.DevicePrefetcher([], "cpu")) == []
+
+
+def test_autocast_invariant_decorator_switches_the_context_off_for_forward_methods_only():
+    """octcubem_amd/_autocast.py on the CPU (the GPU side is tests/test_gpu_autocast.py): a decorated module's forward / forward_* /
+    encode_* run with autocast off -- an fp32 matmul stays fp32 inside `torch.autocast("cpu", dtype=torch.bfloat16)` -- other methods
+    and undecorated modules are untouched, and outside autocast the wrapper adds nothing."""
+    from octcubem_amd._autocast import autocast_invariant
+
+    class Plain(torch.nn.Module):
+        def forward(self, a, b):
+            return a @ b
+
+        def forward_features(self, a, b):
+            return a @ b
+
+        def encode_image(self, a, b):
+            return a @ b
+
+        def helper(self, a, b):
+            return a @ b
+
+    Inv = autocast_invariant(type("Inv", (Plain,), dict(Plain.__dict__)))
+    a, b = torch.randn(8, 8), torch.randn(8, 8)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        assert Plain()(a, b).dtype == torch.bfloat16                      # what autocast does to an ATen island
+        m = Inv()
+        for out in (m(a, b), m.forward_features(a, b), m.encode_image(a, b)):
+            assert out.dtype == torch.float32
+        assert m.helper(a, b).dtype == torch.bfloat16                     # not a forward-like method: untouched
+        assert torch.is_autocast_enabled("cpu")                           # the caller's context is restored
+    exact = a @ b
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        assert torch.equal(Inv()(a, b), exact)
+    assert torch.equal(Inv()(a, b), exact)
+    assert getattr(Inv.forward, "_octmae_no_autocast", False) and not hasattr(Inv.helper, "_octmae_no_autocast")

@@ -14,9 +14,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $R/bench.py --no-cpu-baseline --no-kernel-timing \
       --steps 1 --warmup 0 --global-batch $MB --micro-batch $MB > $OUT/$c.log 2>&1
 done
-python3 - "$OUT" "$R/gpurun_out/${ROUND}_pmc_hbm_traffic.json" "$MB" "$HEAD_ID" <<'PY'
+KH=$(cd $R && python3 -c "import bench; print(bench.kernels_hash())")
+python3 - "$OUT" "$R/gpurun_out/${ROUND}_pmc_hbm_traffic.json" "$MB" "$HEAD_ID" "$KH" <<'PY'
 import csv, glob, json, re, sys, collections
-out, dst, mb, head = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+out, dst, mb, head, kh = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
 acc = {c: collections.defaultdict(lambda: [0, 0.0]) for c in ("FETCH_SIZE", "WRITE_SIZE")}
 for c in acc:
     for f in glob.glob(f"{out}/{c}/**/*counter_collection.csv", recursive=True):
@@ -25,7 +26,7 @@ for c in acc:
                 continue
             k = re.sub(r"^void ", "", row["Kernel_Name"]); k = re.sub(r"^octmae::", "", k); k = k.split("(")[0]
             a = acc[c][k]; a[0] += 1; a[1] += float(row["Counter_Value"])
-res = {"_meta": {"micro_batch": mb, "head": head, "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch"}}
+res = {"_meta": {"micro_batch": mb, "head": head, "kernels_hash": kh, "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch"}}
 for k in sorted(set(acc["FETCH_SIZE"]) | set(acc["WRITE_SIZE"])):
     nf, f = acc["FETCH_SIZE"].get(k, [0, 0.0]); nw, w = acc["WRITE_SIZE"].get(k, [0, 0.0])
     if not nf or not nw:
