@@ -398,4 +398,5 @@ class FlatGradReducer:
             else:
                 dist.broadcast(self._arena.flat, src=src, group=self.group)
             # the arena was written as ONE tensor: no parameter's version counter moved, so say it (the next forward re-casts)
-            self._arena.invalidate_lp()
+            if hasattr(self._arena, "invalidate_lp"):
+                self._arena.invalidate_lp()

@@ -11,6 +11,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_configure(config):
+    # The CPU oracle runs inside many GPU tests, beside child processes that run it too (tests/test_gpu_f16_parity.py, the multi-rank
+    # children of tests/test_gpu_comm.py).  On the 256-thread hosts of the GPU pool torch's default -- one thread per host thread, in
+    # every process -- is oversubscribed: the oracle's ViT-L forward takes 106 s on 256 threads against 8.8 s on 32
+    # (profiles/r05_cpu_threads.txt), and one full-size test of this suite took 220 s waiting for the CPU.
+    try:
+        import torch
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+    except Exception:
+        pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "small_batch_rule: runs with ops.attn_bwd_use_fused's fill rule active (see conftest.py)")
 

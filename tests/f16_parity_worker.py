@@ -23,6 +23,7 @@ if ROOT not in sys.path:
 
 from octcubem_amd import ops  # noqa: E402
 
+torch.set_num_threads(min(16, os.cpu_count() or 1))      # two of these run beside the test session: do not oversubscribe the host
 DEV = "cuda"
 SCALE0 = 65536.0        # torch.cuda.amp.GradScaler's init_scale; --scale0 2**24 finds the largest finite scale (its steady state)
 NAMES = {}              # label -> the tensor a "worst" entry refers to

@@ -30,6 +30,12 @@ class FakeArena:
             e[1] = p
             self.params.append(p)
         self.entries = [tuple(e) for e in self.entries]
+        self.lp_invalidations = 0
+
+    def invalidate_lp(self):
+        """arena.ParamArena's contract: whoever writes the flat weight buffer as ONE tensor (no parameter's version counter moves)
+        says so, and the next forward re-casts the 16-bit operand copy."""
+        self.lp_invalidations += 1
 
 
 class FakeModel:
@@ -51,6 +57,7 @@ def _worker(rank, world, port, q):
     model = FakeModel(arena)
     red = FlatGradReducer(model, n_chunks=3)
     red.broadcast_parameters(0)
+    assert arena.lp_invalidations == 1, "broadcast_parameters must invalidate the operand copy (it writes the arena as one tensor)"
     flat0 = arena.flat.clone()
     # --- step 1: accumulation micro-step (no exchange), then a sync step; param 5 never gets a gradient
     gen = torch.Generator().manual_seed(7 + rank)
