@@ -11,7 +11,9 @@ import time
 
 import torch
 
-from octcubem_amd import lr_sched, misc, models_mae, optim as foptim
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from octcubem_amd import lr_sched, misc, models_mae, ops, optim as foptim
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
@@ -21,7 +23,9 @@ model = models_mae.octcube_vit_large_3dmae().to(dev)
 model.train()
 LR = float(sys.argv[3]) if len(sys.argv) > 3 else 1.5e-4
 opt = foptim.FusedAdamW(misc.add_weight_decay(model, 0.05), lr=LR, betas=(0.9, 0.95))
-scaler = misc.NativeScalerWithGradNormCount(fp32=True)
+# OCTMAE_LIB=octcubem_amd/liboctmae_f16.so: the half-operand build trains through the reference's GradScaler state machine
+scaler = misc.NativeScalerWithGradNormCount(dynamic_loss_scale=ops.LP_IS_F16)
+print(f"operands {ops.BF16}, dynamic loss scale {scaler.enabled}", flush=True)
 params = list(model.parameters())
 g = torch.Generator(device=dev).manual_seed(1)
 t_ = torch.linspace(0, 1, 60, device=dev).view(1, 60, 1, 1)
@@ -57,7 +61,8 @@ for it in range(steps):
     if it % max(1, steps // 20) == 0 or it == steps - 1:
         lv = float(loss.detach())
         hist.append(lv)
-        print(f"step {it:4d}  loss {lv:.5f}  grad-norm {float(norm):.4f}  lr {opt.param_groups[0]['lr']:.2e}  {time.time() - t0:6.1f} s", flush=True)
+        print(f"step {it:4d}  loss {lv:.5f}  grad-norm {float(norm):.4f}  lr {opt.param_groups[0]['lr']:.2e}  scale {scaler.get_scale():g}  "
+              f"{time.time() - t0:6.1f} s", flush=True)
         assert math.isfinite(lv)
 print(f"first {hist[0]:.4f} -> last {hist[-1]:.4f}  ({hist[-1] / var:.3f} of the data variance)")
 # a randomly initialised ViT-L first learns the mean (loss = the data variance) and only then structure: a few hundred steps get it
