@@ -95,7 +95,7 @@ def _linear_bf(x, w, b, out_f32=False):
 def forward_backward(P: Dict[str, torch.Tensor], imgs: torch.Tensor, cfg: O.MAEConfig, mask_ratio: float, noise: torch.Tensor,
                      trace: Optional[dict] = None):
     """Returns (loss, pred [N, L, PD], mask, ids_restore, grads by state_dict key), all float64 (indices int64).
-    `trace` (optional dict) receives the intermediate activations by stage name (diagnostics: tools/rp_model_trace.py)."""
+    `trace` (optional dict) receives the intermediate activations by stage name (diagnostics: tests/tool_rp_model_trace.py)."""
     def tr(name, v):
         if trace is not None:
             trace[name] = v.detach().clone()

@@ -1,6 +1,6 @@
 """Why bench.py's cpu_baseline caps the oracle at 32 torch threads: ONE forward of the ViT-L 3-D MAE oracle (1 volume, fp32) at 32 threads
 and at every host thread, timed once each (the all-core run is oversubscribed on the 256-thread hosts of the pool).
-python tools/cpu_threads_probe.py   -> prints the two timings (kept in profiles/ per round)."""
+python tests/cpu_threads_probe.py   -> prints the two timings (kept in profiles/ per round)."""
 import os
 import sys
 import time
