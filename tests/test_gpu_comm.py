@@ -154,6 +154,7 @@ def test_reducer_one_rank_equals_local_gradient_and_isolates_cold_parameters(com
     scaler = misc.NativeScalerWithGradNormCount(fp32=True, reducer=red)
     opt = foptim.FusedAdamW(misc.add_weight_decay(m, 0.05), lr=0.0, betas=(0.9, 0.95))      # lr 0: the step leaves the weights alone
     for step in range(3):
+        red.timing = step > 0                 # the measurement bench.py switches on for its timed steps (HIP events on both streams)
         opt.zero_grad()
         loss2, _, _ = m(imgs, mask_ratio=0.75, noise=noise)
         scaler(loss2, opt, parameters=list(m.parameters()))
@@ -162,6 +163,15 @@ def test_reducer_one_rank_equals_local_gradient_and_isolates_cold_parameters(com
         if step == 0:
             assert red._cold and red._frozen, "high_res_patch_embed never reports a gradient on 64x64 input"
             after_learning = dict(red.stats)
+    # exposed-communication fields: two frozen-layout steps were recorded; every chunk of the last one has a ready (compute stream)
+    # and a done (communication stream) time after begin_backward(), done >= ready, the cold chunk at the very start
+    ts = red.timing_summary(last=1)
+    assert ts["steps"] == 2 and 0.0 <= ts["exposed_ms_per_step"] <= ts["exposed_ms_max"] < 1e3 and ts["backward_ms_per_step"] > 0.0
+    line = ts["timeline"][0]
+    assert len(line["chunks"]) == len(red.bounds) and line["finish_end_ms"] >= line["finish_begin_ms"] > 0.0
+    for ch in line["chunks"]:
+        assert ch["done_ms"] >= ch["ready_ms"] >= 0.0 and not ch["in_finish"], ch
+    assert any(ch["cold"] and ch["ready_ms"] < 0.5 * line["finish_begin_ms"] for ch in line["chunks"])
     names = {id(p): n for n, p in m.named_parameters()}
     cold_names = sorted(names[k] for k in red._cold)
     assert cold_names == ["high_res_patch_embed.proj.bias", "high_res_patch_embed.proj.weight"], cold_names
