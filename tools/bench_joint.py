@@ -2,11 +2,13 @@
 mask ratio 0.9 for both, Pre-training/scripts/run_chunks_pretraining_vitl_oph_joint_flash_attn.sh:25-66): the joint 3-D + 2-D/512 step of
 engine_pretrain.train_one_epoch_joint -- two forwards, one backward, AdamW.   python tools/bench_joint.py [volumes] [images] [steps]"""
 import json
+import os
 import sys
 import time
 
 import torch
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from octcubem_amd import misc, models_mae, optim as foptim
 
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 1
