@@ -88,6 +88,9 @@ int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2, const floa
  * that may run CONCURRENTLY (different streams) must not share one workspace.  octmae_set_option("gemm_streamk", 0) switches the
  * planning off (1 default; 2: every partial last round -- measurements). */
 int octmae_gemm_streamk_ws_kib(void);     /* size of that workspace in KiB for the current device */
+/* host-side arithmetic only (tests of the planner): tiles handed to the stream-K workgroups for an nt-tile launch of `ktiles` k-tiles on
+ * `cus` CUs under the current "gemm_streamk" option (0 = plain launch); *g_eff = the number of those workgroups */
+int octmae_gemm_streamk_plan(int nt, int ktiles, int cus, int* g_eff);
 int octmae_gemm_bf16_ws(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
                         int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided, int b_kstrided,
                         int epilogue, int splitk, void* sk_ws, long long sk_ws_bytes, void* stream);

@@ -21,6 +21,7 @@ SIGNATURES = {
     "octmae_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "octmae_gemm_bf16_ws": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp],
     "octmae_gemm_streamk_ws_kib": [],
+    "octmae_gemm_streamk_plan": [_i, _i, _i, _vp],
     "octmae_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "octmae_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "octmae_layernorm_bwd_ws_floats": [_i, _i],

@@ -1610,6 +1610,15 @@ extern "C" int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2,
                    nullptr, 1);
 }
 
+// The stream-K plan of a launch with `nt` output tiles of `ktiles` k-tiles on `cus` CUs under the current "gemm_streamk" option (host-side
+// arithmetic only, no GPU is touched): returns the number of tiles handed to the stream-K workgroups (0 = plain launch) and writes the
+// number of those workgroups to *g_eff.  For tests of the planning code: every stream-K workgroup must get a NON-EMPTY span (an empty
+// one would never publish, and the owner of its tile would wait for ever).
+extern "C" int octmae_gemm_streamk_plan(int nt, int ktiles, int cus, int* g_eff) {
+  OCTMAE_CHECK_ARG(nt > 0 && ktiles > 0 && cus > 0 && g_eff);
+  return sk_plan(nt, ktiles, cus, g_eff);
+}
+
 extern "C" int octmae_gemm_streamk_ws_kib(void) { return (int)((sk_ws_bytes_for(device_cus()) + 1023) / 1024); }
 
 extern "C" int octmae_gemm_bf16_ws(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,

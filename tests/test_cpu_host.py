@@ -355,3 +355,40 @@ def test_autocast_invariant_decorator_switches_the_context_off_for_forward_metho
         assert torch.equal(Inv()(a, b), exact)
     assert torch.equal(Inv()(a, b), exact)
     assert getattr(Inv.forward, "_octmae_no_autocast", False) and not hasattr(Inv.helper, "_octmae_no_autocast")
+
+
+def test_streamk_plan_never_leaves_a_workgroup_without_work():
+    """The stream-K kernel's hand-off has ONE way to hang: a workgroup whose span of k-tiles is empty publishes nothing, and the owner
+    of the tile it was planned into waits for its flag for ever.  The planner (csrc/gemm.hip sk_plan, reached without a GPU through
+    octmae_gemm_streamk_plan) must therefore give every stream-K workgroup >= 1 k-tile -- in fact >= 4 -- for every launch shape, under
+    both planning options; and it must leave alone what it was measured not to help (full rounds, nearly empty or nearly full last
+    rounds, short k-loops below one round of tiles)."""
+    from octcubem_amd import _lib
+    lib = _lib.load()
+    g = ctypes.c_int(0)
+    for opt in (1, 2):
+        prev = lib.octmae_set_option(b"gemm_streamk", opt)
+        try:
+            for cus in (256, 304, 64):
+                for ktiles in (1, 3, 4, 8, 16, 24, 32, 48, 64, 100):
+                    for nt in list(range(1, 3 * cus + 7)) + [10 * cus + 4, 40 * cus + cus // 2]:
+                        skt = lib.octmae_gemm_streamk_plan(nt, ktiles, cus, ctypes.byref(g))
+                        assert 0 <= skt <= nt
+                        if skt == 0:
+                            continue
+                        G, W = g.value, skt * ktiles
+                        assert 1 <= G <= cus and W >= 4 * G, (opt, cus, ktiles, nt, skt, G)
+                        spans = [(W * i // G, W * (i + 1) // G) for i in range(G)]
+                        assert all(e - s_ >= 4 for s_, e in spans), (opt, cus, ktiles, nt, skt, G)
+                        assert spans[0][0] == 0 and spans[-1][1] == W and all(spans[i][1] == spans[i + 1][0] for i in range(G - 1))
+                        if nt >= cus:
+                            assert skt == nt % cus and ktiles >= 4
+                            if opt == 1:
+                                assert cus <= 8 * skt and 10 * skt <= 8 * cus      # the window: 1/8 ... 80 % of a round
+                        else:
+                            assert skt == nt and G == 4 * nt and ktiles >= 48       # four equal parts of >= 12 k-tiles
+        finally:
+            lib.octmae_set_option(b"gemm_streamk", prev)
+    assert lib.octmae_set_option(b"gemm_streamk", 0) >= 0
+    assert lib.octmae_gemm_streamk_plan(300, 16, 256, ctypes.byref(g)) == 0          # switched off: never
+    lib.octmae_set_option(b"gemm_streamk", 1)
