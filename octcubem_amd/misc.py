@@ -142,8 +142,9 @@ class NativeScalerWithGradNormCount:
     """``loss_scaler(loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True) -> norm``
     (custom_util/misc.py:308-353).
 
-    The compute type here is bf16, which needs no loss scaling: by default the scale is identically 1 whatever ``fp32`` says.
-    ``dynamic_loss_scale=True`` (with ``fp32=False``) runs the reference's fp16 machinery -- torch.cuda.amp.GradScaler as
+    The shipped compute type is bf16, which needs no loss scaling: with the default library the scale is identically 1 whatever
+    ``fp32`` says.  ``dynamic_loss_scale=True`` -- the default with the half-operand build, ``OCTMAE_LIB=liboctmae_f16.so`` -- (with
+    ``fp32=False``) runs the reference's fp16 machinery -- torch.cuda.amp.GradScaler as
     custom_util/misc.py:311-344 drives it -- for drop-in behaviour and checkpoint round trips (state_dict key "amp_scaler"):
     the loss is multiplied by the scale before backward; gradients are un-scaled inside the fused AdamW kernel (one device-side
     coefficient together with the clip factor, no extra pass); a non-finite gradient norm SKIPS the optimizer step and halves the
@@ -153,8 +154,13 @@ class NativeScalerWithGradNormCount:
     """
     state_dict_key = "amp_scaler"
 
-    def __init__(self, fp32=False, reducer=None, dynamic_loss_scale=False, init_scale=65536.0, growth_factor=2.0,
+    def __init__(self, fp32=False, reducer=None, dynamic_loss_scale=None, init_scale=65536.0, growth_factor=2.0,
                  backoff_factor=0.5, growth_interval=2000):
+        # dynamic_loss_scale=None (default): what the reference's ``GradScaler(enabled=not fp32)`` means for the library in use --
+        # on for the half-operand build (liboctmae_f16.so: gradients underflow without it), off for bfloat16 (fp32's exponent range)
+        if dynamic_loss_scale is None:
+            from . import ops as _ops
+            dynamic_loss_scale = _ops.LP_IS_F16
         self.enabled = bool(dynamic_loss_scale) and not fp32
         self._scale = float(init_scale) if self.enabled else 1.0
         self._growth_factor, self._backoff_factor, self._growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)

@@ -289,7 +289,8 @@ def case_train(out):
     P = O.init_params(cfg, seed=5, bias_std=0.02)
     m = TM.build(cfg, P)
     opt = foptim.FusedAdamW(misc.add_weight_decay(m, 0.05), lr=1e-3, betas=(0.9, 0.95))
-    scaler = misc.NativeScalerWithGradNormCount(dynamic_loss_scale=ops.LP_IS_F16)
+    scaler = misc.NativeScalerWithGradNormCount()          # the reference's call (main_pretrain...:456): dynamic loss scale iff the library computes on half
+    assert scaler.enabled == ops.LP_IS_F16
 
     class A: pass
     a = A(); a.lr = 1e-3; a.min_lr = 0.0; a.warmup_epochs = 1; a.epochs = 10
