@@ -209,9 +209,6 @@ class FlatGradReducer:
         ev.record(stream) if stream is not None else ev.record()
         return ev
 
-    def _comm_torch_stream(self):
-        return self.comm.torch_stream() if self.comm is not None else self._comm_stream
-
     def timing_summary(self, last: int = 1):
         """Resolve the events of the exchanged steps recorded so far (synchronises the device).  Returns
         {"steps": n, "exposed_ms_per_step": mean wait of the compute stream in finish(), "exposed_ms_max": ...,
