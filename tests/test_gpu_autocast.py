@@ -233,6 +233,9 @@ def test_reference_shaped_loop_iteration_under_autocast(golden_dir):
         norm = scaler(loss, opt, parameters=m.parameters(), update_grad=True)
         torch.cuda.synchronize()
         res[mode] = (loss.detach().clone(), norm.detach().clone(), {k: p.detach().clone() for k, p in m.named_parameters()})
-    assert torch.equal(res["plain"][0], res["amp_fp16"][0]) and torch.equal(res["plain"][1], res["amp_fp16"][1])
+    assert torch.equal(res["plain"][0], res["amp_fp16"][0])
+    # the returned norm is a sum of per-chunk partial sums added with fp32 atomics (tensors above 65 536 elements have several chunks):
+    # its last bit depends on their arrival order, with or without autocast -- the update below does not use it (no clipping)
+    assert abs(float(res["plain"][1]) - float(res["amp_fp16"][1])) <= 1e-6 * float(res["plain"][1])
     for k, p in res["plain"][2].items():
         assert torch.equal(p, res["amp_fp16"][2][k]), k
