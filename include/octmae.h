@@ -24,8 +24,10 @@ extern "C" {
  * from this header and refuses a library that reports another number, __graft_entry__.build() and the tests compare the two.
  * 4: octmae_attn_bwd_dq_rowconst.  5: octmae_comm_* (RCCL), octmae_attn_bwd_fused + workspace query.  7: octmae_set_option, octmae_scatter_add_rows, octmae_dec_assemble_bwd.
  * 8: octmae_linear_dgrad_delta, octmae_attn_bwd_fused_delta.  9: octmae_wgrad_accum_pair, octmae_wgrad_split_plan.
- * 10: octmae_lp_dtype, octmae_comm_stream, octmae_mt_adamw_fused, octmae_gemm_bf16_ws + the stream-K workspace arguments. */
-#define OCTMAE_ABI_VERSION 10
+ * 10: octmae_lp_dtype, octmae_comm_stream, octmae_mt_adamw_fused, octmae_gemm_bf16_ws + workspace arguments.
+ * 11: the small-launch GEMM kernel and its split-K workspace (octmae_gemm_split_ws_kib, octmae_gemm_small_plan, "gemm_small");
+ *     the stream-K and 16x16x32 variants of round 4 / 5 left the library (octmae_gemm_streamk_*, "gemm_mfma16", "gemm_streamk"). */
+#define OCTMAE_ABI_VERSION 11
 int octmae_abi_version(void);
 
 /* The 16-bit operand type this library was built for: 0 = bfloat16 (liboctmae.so, the shipped build; BASELINE's headline type),
@@ -44,13 +46,13 @@ int octmae_lp_dtype(void);
  *                          0: two waves per SIMD, 8 x 32 keys (csrc/attn_bwd.hip); the two forms agree bit for bit
  *   "attn_bwd_tail_fused"  1 (default): the one-wave kernels also take the single key past the last full key block and the
  *                          workspace -> bf16 conversion of their (batch, head); 0: the separate launch (same results)
- *   "gemm_mfma16"          0 (default): the 256-tile forward / dgrad GEMMs on v_mfma_f32_32x32x16_bf16 (gemm256p_kernel);
- *                          1: on v_mfma_f32_16x16x32_bf16 (gemm256q_kernel: same tile, staging and epilogues; 3 % faster alone,
- *                          no faster in the training step -- DESIGN.md section 4).  Bit 11 (0x800) of octmae_gemm_bf16's
- *                          `epilogue` argument forces the 32x32x16 form for one call (bits 8-10: tile / main-loop variants)
- *   "gemm_streamk"         1 (default): stream-K over a partial last round of the 256-tile forward / dgrad GEMMs when a workspace is
- *                          lent (octmae_gemm_bf16_ws); 0: never; 2: for every partial last round (measurements)
- *   "gemm_streamk_launches" read-only: returns how many GEMM launches of this process took the stream-K kernel (tests)
+ *   "gemm_small"           1 (default): forward / dgrad launches whose 256 x 256 tiles would leave most CUs idle take the
+ *                          small-launch kernel (gemm128d_kernel: 128 x 128 tiles, deterministic split-K) where the cost model of
+ *                          csrc/gemm.hip (plan128) prices it faster; 0: never (the choice before round 6).  Bits 12 / 13 (0x1000 /
+ *                          0x2000) of octmae_gemm_bf16's `epilogue` argument force that kernel with a 4- / 2-stage ring for one
+ *                          call (its k split is then `splitk`, 1 .. 4), bit 14 (0x4000) forbids it (bits 8-10: the other variants)
+ *   "gemm_small_launches", "gemm_small_split_launches"   read-only: how many GEMM launches of this process took that kernel / took
+ *                          it with a k split (tests)
  *   "wgrad_stagger"        v >= 0 (default 29): split-K weight gradients of >= 8 slices with <= 96 k-tiles each run with slice
  *                          lengths rising by v / 256 k-tiles per output tile of the launch from one slice to the next, so that the
  *                          slices' fp32-atomic epilogues follow one another instead of colliding; 0: equal slices */
@@ -75,25 +77,24 @@ int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2, const floa
                      int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided, int b_kstrided,
                      int epilogue, int splitk, void* stream);
 
-/* octmae_gemm_bf16 with a stream-K workspace lent for this one call (also the trailing `sk_ws, sk_ws_bytes` of the three fused
- * entry points below; NULL / 0 = never stream-K).  The reference's cuBLAS / hipBLASLt picks stream-K kernels by itself for such
- * shapes (nn.Linear forward and backward: video_vit.py:114-135, timm Mlp).  The 256-tile forward / dgrad kernels run one output
- * tile per workgroup, in rounds of the CU count; when the last round would be 1/8 ... 80 % full (nt = 2.52 x 256 tiles for a
- * 1024-column Linear over the token rows of 32 volumes: what one rank of an 8-GPU step runs) -- or when there are fewer tiles than
- * CUs at all (small batches) -- the first CU-count workgroups share the k-tiles of those last tiles evenly instead: fp32 partial
- * tiles travel through `sk_ws` to the workgroup that owns the tile (it holds the tile's first k-tile), which adds them to its
- * accumulators and runs the SAME fused epilogue.  Results differ from the plain launch only by the order of those fp32 additions
- * (deterministic: the split is a function of the shape alone).  sk_ws: octmae_gemm_streamk_ws_kib() KiB of device memory whose
- * last CU-count dwords (the flags) were ZERO when it was first used; contents need not be preserved between calls, but two launches
- * that may run CONCURRENTLY (different streams) must not share one workspace.  octmae_set_option("gemm_streamk", 0) switches the
- * planning off (1 default; 2: every partial last round -- measurements). */
-int octmae_gemm_streamk_ws_kib(void);     /* size of that workspace in KiB for the current device */
-/* host-side arithmetic only (tests of the planner): tiles handed to the stream-K workgroups for an nt-tile launch of `ktiles` k-tiles on
- * `cus` CUs under the current "gemm_streamk" option (0 = plain launch); *g_eff = the number of those workgroups */
-int octmae_gemm_streamk_plan(int nt, int ktiles, int cus, int* g_eff);
+/* octmae_gemm_bf16 with a split-K workspace lent for this one call (also the trailing `split_ws, split_ws_bytes` of the three
+ * fused entry points below; NULL / 0 = no k split).  The reference's cuBLAS / hipBLASLt picks split-K / stream-K kernels by itself
+ * for such shapes (nn.Linear forward and backward: video_vit.py:114-135, timm Mlp); its shipped recipe runs ONE volume per GPU
+ * (scripts/run_chunks_pretraining_vitl_oph_joint_flash_attn.sh:25-30), where a [1281 x 4096] x [4096 x 1024] Linear is 24 tiles of
+ * 256 x 256 for 256 CUs.  Forward / dgrad launches that the cost model prices faster that way run on 128 x 128 tiles
+ * (gemm128d_kernel), long reductions on few tiles additionally split 2-4 ways over k: every slice leaves its fp32 partial tile in
+ * `split_ws`, the slice that ARRIVES last (an arrival counter per tile) adds the partials in slice order and runs the SAME fused
+ * epilogue -- deterministic, no workgroup ever waits for another.  split_ws: octmae_gemm_split_ws_kib() KiB of device memory
+ * whose counters (the last 16 KiB) were ZERO when it was first lent; every launch leaves them zero; contents need not be preserved
+ * between calls, but two launches that may run CONCURRENTLY (different streams) must not share one workspace. */
+int octmae_gemm_split_ws_kib(void);     /* size of that workspace in KiB */
+/* host-side arithmetic only (tests of the planner): 1 if a forward / dgrad launch of NA x NB x K on `cus` CUs takes the small-launch
+ * kernel under the current "gemm_small" option (*slices = its k split, *stages = its ring depth, 4 or 2), 0 otherwise.
+ * have_ws: a split workspace is lent; big_ok: the problem qualifies for the 256-tile kernels */
+int octmae_gemm_small_plan(int NA, int NB, int K, int cus, int have_ws, int big_ok, int* slices, int* stages);
 int octmae_gemm_bf16_ws(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
                         int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided, int b_kstrided,
-                        int epilogue, int splitk, void* sk_ws, long long sk_ws_bytes, void* stream);
+                        int epilogue, int splitk, void* split_ws, long long split_ws_bytes, void* stream);
 
 /* Backward of epilogue 2 together with fc1's bias gradient, WITHOUT atomics (timm Mlp backward: fc2 dgrad, nn.GELU backward,
  * fc1.bias.grad; video_vit.py:174-179 under autograd):
@@ -102,12 +103,12 @@ int octmae_gemm_bf16_ws(const void* A, const void* B, void* C, void* C2, const f
  * need not be initialised) with plain stores; a second launch (octmae_colsum_accum over `ws`) folds the rows into bias_grad:
  * at most 128 atomic adds per address instead of one per 64-row slab -- thousands of slabs adding to one [K] vector serialise
  * per address (~60 ns each: +0.67 ms on the decoder's fc2 at micro-batch 128, +0.13 ms on the encoder's).  Same result as
- * octmae_gemm_bf16(epilogue 4) up to the order of the fp32 additions.  Problems too small for the 256-tile kernel ignore `ws`
- * and sum the columns of dX in a separate pass.  small_tile: kernel-selection bits as in octmae_linear_resid_rowscale, 0 = automatic. */
+ * octmae_gemm_bf16(epilogue 4) up to the order of the fp32 additions.  Problems that take the 128-tile register-staged kernel ignore `ws`
+ * and sum the columns of dX in a separate pass.  variant: kernel-selection bits as in octmae_linear_resid_rowscale, 0 = automatic. */
 int octmae_dgelu_colsum_ws_rows(int M);
 int octmae_linear_dgrad_dgelu(const void* W, const void* dY, void* dX, const void* pre, float* ws, float* bias_grad,
-                              int M, int N, int K, int ldw, int ldy, int ldx, int ldpre, int small_tile, void* sk_ws,
-                              long long sk_ws_bytes, void* stream);
+                              int M, int N, int K, int ldw, int ldy, int ldx, int ldpre, int variant, void* split_ws,
+                              long long split_ws_bytes, void* stream);
 
 /* Two weight gradients over the SAME token rows in one launch (the fc1 / fc2 and the qkv / proj Linears of a Block; backward of
  * video_vit.py:114-135 and timm Mlp under autograd):
@@ -132,17 +133,18 @@ int octmae_wgrad_split_plan(int M, int splitk, int tiles, int* slices, int* boun
  * dX is the gradient of the attention output O; the fused attention backward needs rowsum(dO * O) per query and head, which is a
  * full extra pass over O and dO when computed on its own (0.13 / 0.25 ms per call at the ViT-L shapes) and 8 multiply-adds per
  * lane in this GEMM's epilogue, whose tiles hold whole heads.  delta is computed from the bf16-ROUNDED dX (what the attention
- * backward reads).  Returns -2 when the problem does not take the 256-tile kernel (M or K < 256, N % 64 != 0, K % 8 != 0): the
- * caller then uses octmae_gemm_bf16 and octmae_attn_bwd_fused.  variant: kernel-selection bits (bit 8 forces "not applicable"). */
+ * backward reads).  Returns -2 when the problem takes neither LDS-transposing kernel (N % 64 != 0, K % 8 != 0; M or K < 256
+ * with the small-launch kernel off): the caller then uses octmae_gemm_bf16 and octmae_attn_bwd_fused.  variant: kernel-selection
+ * bits (bit 8 forces "not applicable", bits 12-14 as above). */
 int octmae_linear_dgrad_delta(const void* W, const void* dY, void* dX, const void* O, float* delta, int M, int N, int K, int ldw,
-                              int ldy, int ldx, int ldo, int H, int hd, int variant, void* sk_ws, long long sk_ws_bytes, void* stream);
+                              int ldy, int ldx, int ldo, int H, int hd, int variant, void* split_ws, long long split_ws_bytes, void* stream);
 
 /* Stochastic depth (timm DropPath around both Block branches, video_vit.py:181-184 with drop_path > 0; fine-tune drivers use
  * 0.1-0.2): out f32 [M][N] = res + rowscale[m / rows_per_scale] * (X[M][K] @ W[N][K]^T + bias) -- the per-sample keep mask
- * (0 or 1/keep_prob) applied to the branch inside the residual epilogue.  nn.Linear layouts; small_tile: the kernel-selection bits of `epilogue` above (0x100 / 0x200 / 0x400), 0 = automatic. */
+ * (0 or 1/keep_prob) applied to the branch inside the residual epilogue.  nn.Linear layouts; variant: the kernel-selection bits of `epilogue` above (0x100 ... 0x4000), 0 = automatic. */
 int octmae_linear_resid_rowscale(const void* W, const void* X, float* out, const float* bias, const float* res,
                                  const float* rowscale, int rows_per_scale, int N, int M, int K, int ldw, int ldx, int ldout,
-                                 int ldres, int small_tile, void* sk_ws, long long sk_ws_bytes, void* stream);
+                                 int ldres, int variant, void* split_ws, long long split_ws_bytes, void* stream);
 
 /* ---- LayerNorm over the fp32 residual stream ---------------------------------------------------
  * nn.LayerNorm(eps=1e-6): models_mae_joint_res_flash_attn.py:799, video_vit.py:161,172,181-184, :489, :592.

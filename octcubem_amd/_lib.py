@@ -20,8 +20,8 @@ SIGNATURES = {
     "octmae_set_option": [C.c_char_p, _i],
     "octmae_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "octmae_gemm_bf16_ws": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp],
-    "octmae_gemm_streamk_ws_kib": [],
-    "octmae_gemm_streamk_plan": [_i, _i, _i, _vp],
+    "octmae_gemm_split_ws_kib": [],
+    "octmae_gemm_small_plan": [_i, _i, _i, _i, _i, _i, _vp, _vp],
     "octmae_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "octmae_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "octmae_layernorm_bwd_ws_floats": [_i, _i],

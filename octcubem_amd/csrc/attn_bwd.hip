@@ -817,10 +817,10 @@ int launch_attn_bwd_fused1w(const bf16_t* qkv, const bf16_t* dout, const float* 
 int launch_attn_bwd_fused1w64(const bf16_t* qkv, const bf16_t* dout, const float* rowc, float* dq_ws, bf16_t* dqkv, int B, int N, int NPAD,
                               int H, int nkb, float scale, int tail_key, hipStream_t st);
 std::atomic<int> g_attn_bwd_tail_fused{1};      // the single-key tail inside the one-wave main kernels (0: its own launch)
-extern std::atomic<int> g_gemm_mfma16;      // defined in gemm.hip: 16x16x32 MFMAs in the 256-tile forward / dgrad kernels
 extern std::atomic<int> g_wgrad_stagger;    // defined in gemm.hip: staggered split-K slices of the weight-gradient kernel
-extern std::atomic<int> g_streamk;          // defined in gemm.hip: stream-K over the partial last round of forward / dgrad GEMMs
-extern std::atomic<int> g_sk_launches;
+extern std::atomic<int> g_wgrad_s1_atomic;  // defined in gemm.hip: fp32 atomics in the epilogue of an unsplit weight-gradient launch
+extern std::atomic<int> g_gemm_small;       // defined in gemm.hip: the small-launch kernel (gemm128d_kernel) where the cost model picks it
+extern std::atomic<int> g_small_launches, g_small_split_launches;
 std::atomic<int> g_attn_bwd_hd32_form{1};
 std::atomic<int> g_attn_bwd_hd64_form{1};
 
@@ -891,10 +891,11 @@ extern "C" int octmae_set_option(const char* key, int value) {
   if (__builtin_strcmp(key, "attn_bwd_hd32_form") == 0) return g_attn_bwd_hd32_form.exchange(value ? 1 : 0);
   if (__builtin_strcmp(key, "attn_bwd_hd64_form") == 0) return g_attn_bwd_hd64_form.exchange(value ? 1 : 0);
   if (__builtin_strcmp(key, "attn_bwd_tail_fused") == 0) return g_attn_bwd_tail_fused.exchange(value ? 1 : 0);
-  if (__builtin_strcmp(key, "gemm_mfma16") == 0) return g_gemm_mfma16.exchange(value ? 1 : 0);      // csrc/gemm.hip
   if (__builtin_strcmp(key, "wgrad_stagger") == 0) return g_wgrad_stagger.exchange(value > 0 ? value : 0);
-  if (__builtin_strcmp(key, "gemm_streamk") == 0) return g_streamk.exchange(value < 0 ? 0 : value > 2 ? 2 : value);
-  if (__builtin_strcmp(key, "gemm_streamk_launches") == 0) return g_sk_launches.load();      // read-only counter (tests)
+  if (__builtin_strcmp(key, "wgrad_s1_atomic") == 0) return g_wgrad_s1_atomic.exchange(value < 0 ? 0 : value > 2 ? 2 : value);
+  if (__builtin_strcmp(key, "gemm_small") == 0) return g_gemm_small.exchange(value ? 1 : 0);      // csrc/gemm.hip
+  if (__builtin_strcmp(key, "gemm_small_launches") == 0) return g_small_launches.load();      // read-only counters (tests)
+  if (__builtin_strcmp(key, "gemm_small_split_launches") == 0) return g_small_split_launches.load();
   return -1;
 }
 

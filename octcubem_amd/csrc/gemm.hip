@@ -39,6 +39,8 @@ enum Epi : int {
                      //   256-tile LDS-transposing epilogue only)
 };
 
+constexpr unsigned EPI_OOB_ANY = 0xfffffff0u;   // a byte offset past any buffer range: masks a lane of a raw buffer access
+
 struct GemmParams {
   const bf16_t* A;
   const bf16_t* B;
@@ -57,6 +59,7 @@ struct GemmParams {
   int kstagger;            // split-K: 0 = equal k slices; d > 0 = slice z is d / 256 k-tiles longer than slice z - 1 (split_range)
   int ldc2;                // EPI_DGELU column sums: 0 = C2 is an fp32 [NA] vector (atomics); > 0 = C2 is fp32 [NB / 64][ldc2],
                            // one row of partial sums per 64-row slab, plain stores (folded by a second launch)
+  int atomic1 = 0;         // EPI_ACCUM, UNSPLIT launch: 0 guarded read-modify-write, 1 fp32 atomics, 2 batched buffer read-modify-write (g_wgrad_s1_atomic)
 };
 
 // k-tile range of slice kz of an S-way split.  Equal slices end together and their fp32-atomic epilogues (one dword per L2
@@ -218,6 +221,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     // C[a][b] += X[a][b]: one register across a half-wave is 32 consecutive b of one row a: two 128-B row segments per
     // wave instruction (the full-rate fp32 atomic shape).
     float* C = reinterpret_cast<float*>(p.C);
+    if (!atomic && p.atomic1 == 2) {
+      // unsplit launch, plain read-modify-write in batches of 16 registers through a buffer descriptor: out-of-range elements are
+      // clipped by the offset (no branches), 16 loads are in flight before the first add (the guarded form below makes one
+      // dependent round trip per register: 35 us of a 75 us launch at 21 k-tiles, tools/gemm_small_fit.py)
+      const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(C, 0, (unsigned)((size_t)p.NA * p.ldc * 4), 0x00020000);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int b = b_base + j * 32 + r;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          unsigned off[16];
+          float v[16];
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            const int a = a_base + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+            off[g] = (a < p.NA && b < p.NB) ? (unsigned)(((size_t)a * p.ldc + b) * 4) : EPI_OOB_ANY;
+            v[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, off[g], 0, 0));
+          }
+#pragma unroll
+          for (int g = 0; g < 16; ++g)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[g] + acc[i][j][g]), rc, off[g], 0, 0);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int b = b_base + j * 32 + r;
@@ -386,49 +414,49 @@ constexpr unsigned EPI_OOB = 0x7ffffff0u;
 #define EPI_STORE_AUX 3   // sc0 nt: streaming stores (outputs are >= 100 MB and not re-read before they leave the L2); measured -5..6 % on the bf16 / GELU forwards
 #endif   // byte offset past any num_records above: masks a lane whose columns are >= NA
 
-// Q = false: acc is f32x16[4][2], the 32x32 C layout above.  Q = true: acc is f32x4[8][4], 16 x 16 tiles (a-tile ti, b-tile tj)
-// of v_mfma_f32_16x16x32_bf16: register e of lane (c16 = lane & 15, q4 = lane >> 4) is X[a_base + 16 ti + 4 q4 + e][b_base + 16 tj + c16].
-// Either way a lane holds quads of 4 consecutive a of one output row b, so only the WRITE side of the transpose differs.
-template <int EPI, bool Q = false, class AccT>
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, AccT& acc, int a_base, int b_base, int lane,
+// MI = 32-row blocks of a per wave: 4 (the 256-tile kernels: a wave's block is 128 a x 64 b) or 2 (gemm128d_kernel: 64 a x 64 b).
+// acc is f32x16[MI][2], the 32x32 C layout above: a lane holds quads of 4 consecutive a of one output row b.
+// bf16 image [64 b][32 MI a]: 256-B rows (epi_off) for MI = 4, 128-B rows with the chunk swizzled by (row >> 1) & 7 for MI = 2 (two
+// rows per 64-bank wrap: the 16 rows a half-wave's quads of one a-chunk go to then spread over all banks); read side 4 MI lanes per
+// row, 64 / (4 MI) rows per instruction.  fp32 image [64 b][64 a], 256-B rows, one half of the wave's columns at a time (MI / 2 halves).
+__device__ __forceinline__ int epi_off128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int EPI, int MI = 4>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&acc)[MI][2], int a_base, int b_base, int lane,
                                                   char* wl) {
+  static_assert(MI == 4 || MI == 2, "wave block of 128 or 64 columns");
   const int r = lane & 31, h = lane >> 5;
-  [[maybe_unused]] const int c16 = lane & 15, q4 = lane >> 4;
-  const int rrow = lane >> 4, rc = lane & 15;   // read side: 16 lanes per 256-B row, 4 rows per instruction
   if (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU || EPI == EPI_DELTA) {
-    // bf16 image [64 b][128 a].  EPI_DGELU multiplies by gelu'(pre) on the read side: the product of the bf16-rounded
+    // bf16 image [64 b][32 MI a].  EPI_DGELU multiplies by gelu'(pre) on the read side: the product of the bf16-rounded
     // dgrad with gelu' is rounded once more -- the numerics of an autocast GELU backward, which also reads a bf16 dgrad.
+    constexpr int LPR = 4 * MI, RPI = 64 / LPR, NIT = 64 / RPI;     // lanes per row, rows per instruction, instructions
+    auto off = [](int row, int chunk) { return MI == 4 ? epi_off(row, chunk) : epi_off128(row, chunk); };
+    const int rrow = lane / LPR, rc = lane % LPR;   // read side
     const int a = a_base + rc * 8;
     const bool a_ok = a < p.NA;
     const unsigned o_out = a_ok ? (unsigned)(rrow * p.ldc + a) * 2u : EPI_OOB;
-    u32x4 prev[16];
-    if (EPI == EPI_DGELU || EPI == EPI_DELTA) {   // all 16 pre-activation (attention-output) row segments requested before the transpose
+    u32x4 prev[NIT];
+    if (EPI == EPI_DGELU || EPI == EPI_DELTA) {   // all pre-activation (attention-output) row segments requested before the transpose
       const __amdgpu_buffer_rsrc_t rx = epi_rsrc(p.aux, b_base, p.NB, p.ldaux, 2);
       const unsigned o_aux = a_ok ? (unsigned)(rrow * p.ldaux + a) * 2u : EPI_OOB;
 #pragma unroll
-      for (int it = 0; it < 16; ++it) prev[it] = __builtin_amdgcn_raw_buffer_load_b128(rx, o_aux + it * 4 * p.ldaux * 2, 0, EPI_LOAD_AUX);
+      for (int it = 0; it < NIT; ++it) prev[it] = __builtin_amdgcn_raw_buffer_load_b128(rx, o_aux + it * RPI * p.ldaux * 2, 0, EPI_LOAD_AUX);
     }
-    // All 16 bias quads of the lane are requested together before the first store.  vmcnt retires in order: a bias load
+    // All bias quads of the lane are requested together before the first store.  vmcnt retires in order: a bias load
     // issued after stores -- the second pass of EPI_GELU reloaded them -- waits for every store ahead of it to be
     // acknowledged, and 16 separately guarded loads were 16 dependent L2 round trips per pass (most of the 8.9 k / 21.6 k
     // cycles the plain / GELU epilogue took).
-    f32x4 bias_q[4][4];
+    f32x4 bias_q[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int g = 0; g < 4; ++g) bias_q[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (EPI != EPI_DGELU && EPI != EPI_DELTA && p.bias != nullptr) {
-      if constexpr (!Q) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            bias_q[i][g] = *reinterpret_cast<const f32x4*>(p.bias + min(a_base + i * 32 + 8 * g + 4 * h, p.NA - 4));
-      } else {
-#pragma unroll
-        for (int ti = 0; ti < 8; ++ti)
-          bias_q[ti >> 2][ti & 3] = *reinterpret_cast<const f32x4*>(p.bias + min(a_base + ti * 16 + 4 * q4, p.NA - 4));
-      }
+        for (int g = 0; g < 4; ++g)
+          bias_q[i][g] = *reinterpret_cast<const f32x4*>(p.bias + min(a_base + i * 32 + 8 * g + 4 * h, p.NA - 4));
     }
 #pragma unroll
     for (int pass = 0; pass < (EPI == EPI_GELU ? 2 : 1); ++pass) {
@@ -438,33 +466,25 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, AccT& acc
           const f32x2 y0 = gelu_f2(f32x2{bflo(w[0]), bfhi(w[0])}), y1 = gelu_f2(f32x2{bflo(w[1]), bfhi(w[1])});
           w = u32x2{pack2bf(y0[0], y0[1]), pack2bf(y1[0], y1[1])};
         }
-        *reinterpret_cast<u32x2*>(wl + epi_off(row, chunk) + 8 * half8) = w;
+        *reinterpret_cast<u32x2*>(wl + off(row, chunk) + 8 * half8) = w;
       };
-      if constexpr (!Q) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < MI; ++i) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < 4; ++g) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-              put(f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]}, bias_q[i][g], j * 32 + r,
-                  4 * i + g, h);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int ti = 0; ti < 8; ++ti) {
-#pragma unroll
-          for (int tj = 0; tj < 4; ++tj) put(acc[ti][tj], bias_q[ti >> 2][ti & 3], tj * 16 + c16, 2 * ti + (q4 >> 1), q4 & 1);
+          for (int j = 0; j < 2; ++j)
+            put(f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]}, bias_q[i][g], j * 32 + r,
+                4 * i + g, h);
         }
       }
       __builtin_amdgcn_wave_barrier();
       const __amdgpu_buffer_rsrc_t ro = epi_rsrc(pass == 0 ? p.C : p.C2, b_base, p.NB, p.ldc, 2);
       float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // EPI_DGELU: column sums of what is stored (the fc1 bias gradient)
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int row = it * 4 + rrow;
-        u32x4 v = *reinterpret_cast<const u32x4*>(wl + epi_off(row, rc));
+      for (int it = 0; it < NIT; ++it) {
+        const int row = it * RPI + rrow;
+        u32x4 v = *reinterpret_cast<const u32x4*>(wl + off(row, rc));
         if (EPI == EPI_DGELU) {
           const u32x4 pre = prev[it];   // zeros outside the matrix: gelu'(0) * v is stored nowhere and summed nowhere
 #pragma unroll
@@ -494,12 +514,13 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, AccT& acc
           if ((rc & (lph - 1)) == 0 && a_ok && b_base + row < p.NB)
             reinterpret_cast<float*>(p.C2)[(size_t)(b_base + row) * p.ldc2 + (a >> (p.hd == 64 ? 6 : 5))] = -sum;
         }
-        __builtin_amdgcn_raw_buffer_store_b128(v, ro, o_out + it * 4 * p.ldc * 2, 0, EPI_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v, ro, o_out + it * RPI * p.ldc * 2, 0, EPI_STORE_AUX);
       }
-      if (EPI == EPI_DGELU && p.C2 != nullptr) {      // 4 row groups (lane >> 4) hold partial sums of the same 8 columns
+      if (EPI == EPI_DGELU && p.C2 != nullptr) {      // the row groups (lane / LPR) hold partial sums of the same 8 columns
         float* colsum = reinterpret_cast<float*>(p.C2);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
+          if (MI == 2) cs[e] += __shfl_xor(cs[e], 8, 64);
           cs[e] += __shfl_xor(cs[e], 16, 64);
           cs[e] += __shfl_xor(cs[e], 32, 64);
         }
@@ -520,11 +541,13 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, AccT& acc
       __builtin_amdgcn_wave_barrier();
     }
   } else {
-    // fp32 image [64 b][64 a], two halves of the wave's 128 columns.  EPI_RESID: the residual row segments of a half (and
+    // fp32 image [64 b][64 a], one half of the wave's columns at a time.  EPI_RESID: the residual row segments of a half (and
     // the per-row stochastic-depth scales) are requested before that half is transposed, half 1 while half 0 is stored.
+    constexpr int NH = MI / 2;
+    const int rrow = lane >> 4, rc = lane & 15;   // read side: 16 lanes per 256-B row, 4 rows per instruction
     const __amdgpu_buffer_rsrc_t ro = epi_rsrc(p.C, b_base, p.NB, p.ldc, 4);
     const __amdgpu_buffer_rsrc_t rx = epi_rsrc(EPI == EPI_RESID ? p.aux : p.C, b_base, p.NB, EPI == EPI_RESID ? p.ldaux : p.ldc, 4);
-    u32x4 resv[2][16];
+    u32x4 resv[NH][16];
     float rsc[16];
     auto load_res = [&](int half) {
       const int a = a_base + half * 64 + rc * 4;
@@ -532,12 +555,14 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, AccT& acc
 #pragma unroll
       for (int it = 0; it < 16; ++it) resv[half][it] = __builtin_amdgcn_raw_buffer_load_b128(rx, o_aux + it * 4 * p.ldaux * 4, 0, EPI_LOAD_AUX);
     };
-    // the bias is added on the read side, where a lane keeps the same 4 columns for all 16 row segments of a half: two
-    // loads per lane, issued ahead of the residual requests (vmcnt retires in order)
-    f32x4 bias4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // the bias is added on the read side, where a lane keeps the same 4 columns for all 16 row segments of a half: one
+    // load per lane and half, issued ahead of the residual requests (vmcnt retires in order)
+    f32x4 bias4[NH];
+#pragma unroll
+    for (int half = 0; half < NH; ++half) bias4[half] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.bias != nullptr) {
 #pragma unroll
-      for (int half = 0; half < 2; ++half)
+      for (int half = 0; half < NH; ++half)
         bias4[half] = *reinterpret_cast<const f32x4*>(p.bias + min(a_base + half * 64 + rc * 4, p.NA - 4));
     }
     if (EPI == EPI_RESID) {
@@ -559,31 +584,22 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, AccT& acc
       }
     }
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      if constexpr (!Q) {
+    for (int half = 0; half < NH; ++half) {
 #pragma unroll
-        for (int i2 = 0; i2 < 2; ++i2) {
-          const int i = half * 2 + i2;
+      for (int i2 = 0; i2 < 2; ++i2) {
+        const int i = half * 2 + i2;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < 4; ++g) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              f32x4 w = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-              const int row = j * 32 + r;
-              *reinterpret_cast<f32x4*>(wl + epi_off(row, i2 * 8 + 2 * g + h)) = w;
-            }
+          for (int j = 0; j < 2; ++j) {
+            f32x4 w = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            const int row = j * 32 + r;
+            *reinterpret_cast<f32x4*>(wl + epi_off(row, i2 * 8 + 2 * g + h)) = w;
           }
-        }
-      } else {
-#pragma unroll
-        for (int t2 = 0; t2 < 4; ++t2) {
-#pragma unroll
-          for (int tj = 0; tj < 4; ++tj)
-            *reinterpret_cast<f32x4*>(wl + epi_off(tj * 16 + c16, t2 * 4 + q4)) = acc[half * 4 + t2][tj];
         }
       }
       __builtin_amdgcn_wave_barrier();
-      if (EPI == EPI_RESID && half == 0) load_res(1);
+      if (EPI == EPI_RESID && half + 1 < NH) load_res(half + 1);
       const int a = a_base + half * 64 + rc * 4;
       const unsigned o_out = a < p.NA ? (unsigned)(rrow * p.ldc + a) * 4u : EPI_OOB;
 #pragma unroll
@@ -741,86 +757,11 @@ __device__ __forceinline__ void glds16(const gi32x4& rsrc, unsigned lds_addr, un
 #pragma clang diagnostic pop
 }
 
-// ---- stream-K (gemm256p_sk_kernel below): a workgroup computes a SEGMENT of a tile's k range.  The segment that holds the tile's
-// first k-tile OWNS the tile: it gathers the fp32 partial tiles of the others ("peers": the workgroups next in line, each of which
-// computes its share of this tile FIRST), adds them to its accumulators and runs the epilogue.  A peer leaves its 256 x 256 fp32
-// partial in its own slot of a caller-owned workspace (lane-contiguous 16-byte stores, 8 KiB per store instruction) and raises the
-// slot's flag to the launch's generation number (visibility across CUs / XCDs: see sk_publish below).
-struct SkSeg {
-  int mode;               // 0 whole tile (no hand-off), 1 peer (publish the partial), 2 owner (gather `npeers` partials first)
-  int slot;               // mode 1: this workgroup's slot
-  int peer0, npeers;      // mode 2: slots peer0 .. peer0 + npeers - 1
-  float* slots;           // [G][65536] fp32
-  unsigned* flags;        // [G]
-  unsigned gen;           // generation of this launch (flags are never reset: a stale flag holds an older generation)
-};
-constexpr int SK_SLOT_FLOATS = T2 * T2;
-
-// The partial tiles travel by WRITE-THROUGH (`sc1`) 16-byte stores and `sc1` loads, the flag by an `sc1` store and an `sc1` poll
-// (MI355X_MICROARCH.md, table of hand-offs measured with sc1 loads in place of the acquire, first row: one lane of the storing
-// workgroup signals for all its stores after every storing wave's vmcnt(0) and a workgroup barrier; the polling wave loads after its
-// poll has matched, the others after a workgroup barrier it then joins; hipMalloc memory; one workgroup per CU).  The first version
-// used plain stores + an agent-scope release / acquire pair: each release (buffer_wbl2) writes back the XCD's whole L2 -- full of
-// the other 31 workgroups' partial tiles and of streamed GEMM outputs -- and the 32 of them per XCD ran one after the other:
-// +135 us per launch whatever its size (tools/streamk_ab.py, profiles/r05_streamk_ab.txt).
-constexpr int SK_AUX = 16;      // sc1
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_rsrc(const SkSeg& sk, int slot) {
-  const unsigned long long q = reinterpret_cast<unsigned long long>(sk.slots) + (unsigned long long)slot * SK_SLOT_FLOATS * 4;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)q), hi = __builtin_amdgcn_readfirstlane((unsigned)(q >> 32));
-  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, SK_SLOT_FLOATS * 4, 0x00020000);
-}
-
-__device__ __forceinline__ void sk_publish(const SkSeg& sk, f32x16 (&acc)[4][2], int tid) {
-  const __amdgpu_buffer_rsrc_t rs = sk_rsrc(sk, sk.slot);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (((i * 2 + j) * 4 + q) * 512 + tid) * 16, 0, SK_AUX);
-      }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its stores have been written through
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(sk.flags + sk.slot, sk.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // global_store sc1
-}
-
-__device__ __forceinline__ void sk_gather(const SkSeg& sk, f32x16 (&acc)[4][2], int tid) {
-  for (int n = 0; n < sk.npeers; ++n) {
-    const int s = sk.peer0 + n;
-    if (tid == 0) {
-      while (__hip_atomic_load(sk.flags + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.gen) __builtin_amdgcn_s_sleep(4);
-    }
-    __syncthreads();
-    const __amdgpu_buffer_rsrc_t rs = sk_rsrc(sk, s);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        u32x4 v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (((i * 2 + j) * 4 + q) * 512 + tid) * 16, 0, SK_AUX);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 f = __builtin_bit_cast(f32x4, v[q]);
-          acc[i][j][4 * q] += f[0]; acc[i][j][4 * q + 1] += f[1]; acc[i][j][4 * q + 2] += f[2]; acc[i][j][4 * q + 3] += f[3];
-        }
-        __builtin_amdgcn_sched_barrier(0);        // 16 registers of loads in flight at a time, not all 128
-      }
-  }
-}
-
 // the tile body: tile t of p, k-tiles kt0 .. kt1 - 1   (smem: [stage 2][operand 2][half 2] x 16 KiB); partial = split-K (atomics)
-template <bool A_KS, bool B_KS, int EPI, bool OUT_AB, bool SK = false>
+template <bool A_KS, bool B_KS, int EPI, bool OUT_AB>
 __device__ __forceinline__ void gemm256p_body(const GemmParams& p, const int t, const int kt0, const int kt1, const bool partial,
-                                              char* smem, const SkSeg* sk = nullptr) {
-  int tid_ = threadIdx.x;
-  // stream-K calls this body in a loop over the segments of a workgroup's span: without this the compiler hoists every lane-derived
-  // address of the body (fragment offsets, DMA offsets, the epilogue's) out of that loop and keeps them alive across the k-loop --
-  // 270 spilled registers, whose scratch traffic would sit inside the hand-counted vmcnt ring
-  if constexpr (SK) asm volatile("" : "+v"(tid_));
-  const int tid = tid_, lane = tid & 63;
+                                              char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wid >> 2, wb = wid & 3;          // wa = 1: the late group (waves 4-7)
   int ta, tb;
@@ -982,12 +923,6 @@ __device__ __forceinline__ void gemm256p_body(const GemmParams& p, const int t, 
       }
     }
   }
-  if constexpr (SK) {
-    if (sk->mode == 1) { sk_publish(*sk, acc, tid); return; }
-    if (sk->mode == 2) sk_gather(*sk, acc, tid);
-    gemm_epilogue_lds<EPI>(p, acc, a0 + wa * 128, b0 + wb * 64, lane, smem + wid * 16384);     // (the host plans stream-K only for NA % 8 == 0)
-    return;
-  }
   if (OUT_AB || (p.NA & 7) != 0) {
     gemm_epilogue<EPI, OUT_AB, 4, 2>(p, acc, a0 + wa * 128, b0 + wb * 64, lane, partial);
   } else {
@@ -1012,62 +947,9 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(const GemmParams p) {
   }
   int kt0, kt1;
   split_range(p, kz, (int)gridDim.z, kt0, kt1);
-  gemm256p_body<A_KS, B_KS, EPI, OUT_AB>(p, t, kt0, kt1, gridDim.z > 1, smem);
+  gemm256p_body<A_KS, B_KS, EPI, OUT_AB>(p, t, kt0, kt1, gridDim.z > 1 || p.atomic1 == 1, smem);
 }
 
-// ---- stream-K over the partial last round (forward / dgrad kinds: one output tile per workgroup, fused epilogue) ----------------
-// nt tiles on G CUs run as ceil(nt / G) rounds; with nt = 2.52 G (a 1024-column Linear over the 40 992 token rows of 32 volumes: the
-// per-rank shape of an 8-GPU step) the third round is half empty and the GEMM takes 3 tile times for 2.52 tiles' worth of work.
-// Here the first G workgroups share the k-tiles of the LAST sk_tiles tiles EVENLY (workgroup i: iterations W i / G .. W (i + 1) / G of
-// the W = sk_tiles x ktiles of that region, in tile-major order), the other nt - sk_tiles tiles follow one per workgroup as before, and
-// every CU is busy for nt / G tile times (+ the hand-off).  A workgroup's span is cut at tile borders into segments (SkSeg); it
-// computes the segment that does NOT start a tile first and publishes it at once, so by the time an owner reaches its gather the
-// peers' partials have been waiting for a while.  No deadlock for any dispatch order that starts lower block ids first: a peer's
-// segment never waits, and the G stream-K workgroups are the first G blocks of the grid.
-struct SkLaunch {
-  int G, sk_tiles, nt_dp;
-  float* slots;
-  unsigned* flags;
-  unsigned gen;
-};
-template <bool A_KS, bool B_KS, int EPI>
-__global__ __launch_bounds__(512, 1) void gemm256p_sk_kernel(const GemmParams p, const SkLaunch s) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // ONE instance of the tile body serves both kinds of workgroup (two inlined copies of it do not fit the register budget): a
-  // workgroup of the full rounds is a span of exactly one whole tile
-  int i, it, e1, tbase;
-  const long long W = (long long)s.sk_tiles * p.ktiles;
-  if ((int)blockIdx.x >= s.G) {                                   // the full rounds: one tile per workgroup
-    tbase = xcd_remap((int)blockIdx.x - s.G, s.nt_dp);
-    i = s.G; it = 0; e1 = p.ktiles;
-  } else {
-    i = xcd_remap((int)blockIdx.x, s.G);                          // neighbours in the iteration space share an XCD (and its L2)
-    tbase = s.nt_dp;
-    e1 = (int)(W * (i + 1) / s.G);
-    it = (int)(W * i / s.G);
-  }
-  while (it < e1) {
-    const int T = it / p.ktiles, k0 = it - T * p.ktiles;
-    const int tile_end = (T + 1) * p.ktiles;
-    const int k1 = (e1 < tile_end ? e1 : tile_end) - T * p.ktiles;
-    SkSeg sk;
-    sk.slots = s.slots; sk.flags = s.flags; sk.gen = s.gen; sk.slot = i; sk.peer0 = i + 1; sk.npeers = 0;
-    if (k0 > 0) {
-      sk.mode = 1;
-    } else if (k1 < p.ktiles) {
-      sk.mode = 2;
-      int j = i + 1;
-      while (j < s.G && (int)(W * j / s.G) < tile_end) ++j;       // every later workgroup whose span starts inside this tile
-      sk.npeers = j - (i + 1);
-    } else {
-      sk.mode = 0;
-    }
-    gemm256p_body<A_KS, B_KS, EPI, false, true>(p, tbase + T, k0, k1, false, smem, &sk);
-    it = T * p.ktiles + k1;
-    __builtin_amdgcn_s_waitcnt(0xC07F);                           // lgkmcnt(0): the epilogue's LDS reads
-    __syncthreads();                                              // the next segment's LDS-DMA lands in every wave's epilogue region
-  }
-}
 
 // Two weight gradients with the same reduction length (the same token rows) in ONE launch: the tiles of both share the split, so the
 // pair runs tiles0 + tiles1 tiles x S slices where each alone would run tiles x 2 S -- half the fp32-atomic epilogues (256 KiB per
@@ -1087,208 +969,201 @@ __global__ __launch_bounds__(512, 1) void gemm256p_wgrad_pair_kernel(const GemmP
   int kt0, kt1;
   if (!second) {
     split_range(pp.p0, kz, pp.S, kt0, kt1);
-    gemm256p_body<true, true, EPI_ACCUM, true>(pp.p0, t, kt0, kt1, pp.S > 1, smem);
+    gemm256p_body<true, true, EPI_ACCUM, true>(pp.p0, t, kt0, kt1, pp.S > 1 || pp.p0.atomic1 == 1, smem);
   } else {
     split_range(pp.p1, kz, pp.S, kt0, kt1);
-    gemm256p_body<true, true, EPI_ACCUM, true>(pp.p1, t, kt0, kt1, pp.S > 1, smem);
+    gemm256p_body<true, true, EPI_ACCUM, true>(pp.p1, t, kt0, kt1, pp.S > 1 || pp.p1.atomic1 == 1, smem);
   }
 }
 
 
 // =====================================================================================================
-// gemm256q_kernel: the phased main loop above on v_mfma_f32_16x16x32_bf16 (round 4).  Same tile (256 x 256 x 64), same staging,
-// same phases and barriers, same LDS-DMA ring; a phase is 16 MFMAs of 16 cycles instead of 8 of 32.  Why: these kernels are
-// POWER-limited, not issue-limited -- the same binary runs 19-26 % faster on all-zero operands (profiles/r04_dvfs_probe.txt) --
-// and the chip holds a higher clock on the 16x16x32 shape (MI355X_MICROARCH.md, DVFS give-back item 7; tools/ubench/
-// bwd_block_shapes.hip measured +14 % clock for +6 % cycles): per multiply-accumulate it moves 0.25 B of operands and 0.25 B of
-// accumulator through the register file against 0.125 B + 0.5 B for 32x32x16.
-//   * A operand (lane l: row l & 15, k = 8 (l >> 4) .. + 7 of a 32-deep k-step): one ds_read_b128 per 16 rows and k-step from the
-//     k-contiguous image (conflict-free on the shipped swizzle: tools/lds_bank_check.py), two transposed reads from the
-//     k-strided image, whose chunk swizzle gains the (kr >> 2) & 3 term of cdna_hip_programming.md T10 image (b): the four
-//     lane groups of a wave read the SAME 16 columns of k rows 8 apart, 2-way conflicts on the shipped swizzle;
-//   * accumulators: f32x4 acc[8][4] (a-tile, b-tile); the epilogue is gemm_epilogue_lds<EPI, true> (write side of the transpose).
-// Built for the forward and dgrad kinds (OUT_AB = false, NA % 8 == 0); weight gradients stay on gemm256p_kernel (their fp32
-// atomics want 128-B row segments per register: 32 consecutive b, the 32x32 C layout).
+// gemm128d_kernel (round 6): the SMALL-LAUNCH kernel of the forward / dgrad kinds.  A launch of the 256-tile kernels costs one
+// tile time -- k-tiles x ~1.2 us -- however few of the 256 CUs it fills: one volume per step (the reference's shipped recipe,
+// scripts/run_chunks_pretraining_vitl_oph_joint_flash_attn.sh:25-30) gives the encoder's proj / fc2 forwards 24 tiles and the
+// GEMMs 49 % of the step (profiles/r05_batch1_kernel_stats.csv).  Here: tile 128(a) x 128(b) x 64(k), 4 waves (2 x 2, ONE per
+// SIMD), each wave 64 x 64 = 2 x 2 v_mfma_f32_32x32x16 blocks; four times the workgroups, a quarter of the k-tile time each.
+//   * operands by LDS-DMA into a ring of NST stages of (A 16 KiB | B 16 KiB) -- the half-images of the phased kernel, same
+//     swizzles, same fragment reads -- NST - 1 k-tiles ahead, one counted vmcnt and ONE workgroup barrier per k-tile.  NST = 4
+//     (128 KiB, one workgroup per CU: a wave per SIMD hides HBM / L2 latency only through the ring's depth) for launches of at
+//     most one workgroup per CU; NST = 2 (64 KiB, two co-resident workgroups per CU) for launches between one and two per CU;
+//   * trailing ring slots are requested with soffset = num_records: every lane out of range, zero-filled, no memory traffic;
+//   * the coalescing LDS-transposing epilogue of the 256-tile kernels with a 64-column wave block (gemm_epilogue_lds<EPI, 2>),
+//     every fused epilogue of the forward / dgrad kinds;
+//   * split-K (S <= 4 slices of a tile's k range, chosen by the host for long reductions on few tiles: plan128 below),
+//     DETERMINISTIC: every slice leaves its fp32 partial tile in a caller-lent workspace (16-byte write-through stores), one lane
+//     adds to the tile's arrival counter after every storing wave's vmcnt(0) and a workgroup barrier, and the workgroup whose add
+//     came LAST -- told by the value the add returned -- sums the S partials in slice order (its own from registers, the others
+//     by sc1 loads after a barrier that lane joins: MI355X_MICROARCH.md, hand-offs measured with sc1 loads, first row), runs the
+//     fused epilogue and resets the counter.  Nobody ever waits for another workgroup: no co-residency assumption, no spin.
+// Requires NA % 8 == 0, K % 64 == 0 for k-contiguous operands, operands within a 32-bit buffer range (host: gemm128_ok).
 // =====================================================================================================
-__device__ __forceinline__ int ksQ_off(int kr, int c) { return kr * 256 + ((c ^ (((kr & 3) << 2) | ((kr >> 2) & 3))) << 4); }  // [64 k][128 rows]
+struct SplitWs {
+  float* slots;       // [tiles x S] fp32 partial tiles of 128 x 128 (S > 1)
+  unsigned* ctr;      // [tiles] arrival counters: zero before the launch, zero again after it
+};
+constexpr int T1 = 128;
+constexpr int D_STAGE = 2 * TILE_BYTES;      // 32 KiB: A image | B image
+constexpr int D_SLOT_FLOATS = T1 * T1;
 
-// fragment of 16 rows starting at in-half row rb for the 32-deep k-step s2 (0 / 1) of one 16 KiB half-image
-template <bool KS>
-__device__ __forceinline__ bf16x8 read_fragQ(const char* lds, int rb, int s2, int lane) {
-  if (!KS) {
-    const int r = rb + (lane & 15), c = 4 * s2 + (lane >> 4);
-    return *reinterpret_cast<const bf16x8*>(lds + kcH_off(r, c));
-  } else {
-    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-    const int c = (rb >> 3) + (pp >> 1);
-    const int kr0 = 32 * s2 + 8 * g + q;
-    const bf16x4 lo = lds_tr_read(lds + ksQ_off(kr0, c) + (pp & 1) * 8);
-    const bf16x4 hi = lds_tr_read(lds + ksQ_off(kr0 + 4, c) + (pp & 1) * 8);
-    return cat4(lo, hi);
-  }
-}
-
-__device__ __forceinline__ f32x4 mfma16q(bf16x8 a, bf16x8 b, f32x4 c) { return mfma16x16(a, b, c); }
-
-template <bool A_KS, bool B_KS, int EPI>
-__global__ __launch_bounds__(512, 1) void gemm256q_kernel(const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [stage 2][operand 2][half 2] x 16 KiB
+template <bool A_KS, bool B_KS, int EPI, int NST>
+__global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm128d_kernel(const GemmParams p, const SplitWs w, const int S) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ unsigned s_arrival;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wa = wid >> 2, wb = wid & 3;          // wa = 1: the late group (waves 4-7)
-
+  const int wa = wid >> 1, wb = wid & 1;
   const int nt = p.tiles_a * p.tiles_b;
-  const int t = xcd_remap(blockIdx.x, nt);
+  int t, kz;
+  if (S > 1) {      // k-slice-major over the XCD-contiguous index, as the weight gradients: an XCD's workgroups share panels
+    const int L = xcd_remap((int)blockIdx.x, nt * S);
+    kz = L / nt; t = L - kz * nt;
+  } else {
+    t = xcd_remap((int)blockIdx.x, nt); kz = 0;
+  }
   int ta, tb;
   tile_coord(p, t, ta, tb);
-  const int a0 = ta * T2, b0 = tb * T2;
-  const int nk = p.ktiles;
+  const int a0 = ta * T1, b0 = tb * T1;
+  int kt0, kt1;
+  split_range(p, kz, S, kt0, kt1);
+  const int nk = kt1 - kt0;
 
-  f32x4 acc[8][4];
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  {
+  if (nk > 0) {
     const unsigned a_bytes = (unsigned)((size_t)(A_KS ? p.K : p.NA) * p.lda * 2);
     const unsigned b_bytes = (unsigned)((size_t)(B_KS ? p.K : p.NB) * p.ldb * 2);
     const unsigned long long pa = (unsigned long long)p.A, pb = (unsigned long long)p.B;
     const gi32x4 ra = {(int)(unsigned)pa, (int)(unsigned)(pa >> 32), (int)a_bytes, 0x00020000};
     const gi32x4 rb = {(int)(unsigned)pb, (int)(unsigned)(pb >> 32), (int)b_bytes, 0x00020000};
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    // per-lane source offsets of this wave's two 1-KiB pieces of each half-image (k-tile 0), and the k-tile stride
-    unsigned va[2][2], vb[2][2];
+    // per-lane source offsets of this wave's four 1-KiB pieces of each image (k-tile kt0), and the k-tile stride
+    unsigned va[4], vb[4];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const int j = 2 * wid + n;
-        if (!A_KS) {
-          const int r = 8 * j + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
-          va[hf][n] = (unsigned)(((size_t)(a0 + hf * 128 + r) * p.lda + c * 8) * 2);
-        } else {
-          const int kr = 4 * j + (lane >> 4), c = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
-          va[hf][n] = (unsigned)(((size_t)kr * p.lda + a0 + hf * 128 + c * 8) * 2);
-        }
-        if (!B_KS) {
-          const int r = 8 * j + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
-          vb[hf][n] = (unsigned)(((size_t)(b0 + hf * 128 + r) * p.ldb + c * 8) * 2);
-        } else {
-          const int kr = 4 * j + (lane >> 4), c = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
-          vb[hf][n] = (unsigned)(((size_t)kr * p.ldb + b0 + hf * 128 + c * 8) * 2);
-        }
+    for (int n = 0; n < 4; ++n) {
+      const int j = 4 * wid + n;
+      if (!A_KS) {
+        const int r = 8 * j + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+        va[n] = (unsigned)(((size_t)(a0 + r) * p.lda + (size_t)kt0 * TK + c * 8) * 2);
+      } else {
+        const int kr = 4 * j + (lane >> 4), c = (lane & 15) ^ ((kr & 3) << 2);
+        va[n] = (unsigned)((((size_t)kt0 * TK + kr) * p.lda + a0 + c * 8) * 2);
       }
+      if (!B_KS) {
+        const int r = 8 * j + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+        vb[n] = (unsigned)(((size_t)(b0 + r) * p.ldb + (size_t)kt0 * TK + c * 8) * 2);
+      } else {
+        const int kr = 4 * j + (lane >> 4), c = (lane & 15) ^ ((kr & 3) << 2);
+        vb[n] = (unsigned)((((size_t)kt0 * TK + kr) * p.ldb + b0 + c * 8) * 2);
+      }
+    }
     const unsigned ka = (unsigned)(A_KS ? (size_t)TK * p.lda * 2 : (size_t)TK * 2);
     const unsigned kb = (unsigned)(B_KS ? (size_t)TK * p.ldb * 2 : (size_t)TK * 2);
-    auto stage = [&](int op, int kt, int buf) {            // both halves of operand `op` of k-tile kt -> stage buf (4 loads)
-      const unsigned base = lds0 + (unsigned)(buf * 65536 + op * 32768 + 2 * wid * 1024);
-      const unsigned so = (unsigned)kt * (op ? kb : ka);
+    auto stage = [&](int it) {            // k-tile kt0 + it -> ring slot it % NST (8 loads per wave)
+      const unsigned base = lds0 + (unsigned)((it % NST) * D_STAGE + 4 * wid * 1024);
+      const bool live = it < nk;
+      const unsigned sa = live ? (unsigned)it * ka : a_bytes, sb = live ? (unsigned)it * kb : b_bytes;
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
+      for (int n = 0; n < 4; ++n) glds16(ra, base + (unsigned)(n * 1024), va[n], sa);
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
-          glds16(op ? rb : ra, base + (unsigned)(hf * 16384 + n * 1024), op ? vb[hf][n] : va[hf][n], so);
+      for (int n = 0; n < 4; ++n) glds16(rb, base + (unsigned)(TILE_BYTES + n * 1024), vb[n], sb);
     };
-    // prologue: B(0), A(0), B(1) -- the order the loop keeps (B a k-tile ahead of A)
-    stage(1, 0, 0);
-    stage(0, 0, 0);
-    stage(1, 1, 1);
-    __builtin_amdgcn_s_waitcnt(0x0F74);       // vmcnt(4) (lgkmcnt/expcnt untouched): A(0), B(0) have landed
-    __builtin_amdgcn_s_barrier();
-    if (wa) __builtin_amdgcn_s_barrier();     // the late group starts one barrier behind
-
-    const int rowB = (wb & 1) * 64;           // this wave's 64 b-rows inside its B half
-    bf16x8 fa[4][2], fb[4][2];
+#pragma unroll
+    for (int it = 0; it < NST - 1; ++it) stage(it);
     for (int it = 0; it < nk; ++it) {
-      const int buf = it & 1;
-      const char* cA = smem + buf * 65536 + wa * 16384;                    // my A half: rows wa*128 ..
-      const char* cB = smem + buf * 65536 + 32768 + (wb >> 1) * 16384;     // my B half
-      // ---- phase 1: a 0..63 x b 0..31
-#pragma unroll
-      for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) fb[tj][s] = read_fragQ<B_KS>(cB, rowB + 16 * tj, s, lane);
-#pragma unroll
-      for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) fa[ti][s] = read_fragQ<A_KS>(cA, 16 * ti, s, lane);
-      stage(0, it + 1, buf ^ 1);
-      __builtin_amdgcn_sched_barrier(0);
+      // tile `it` has landed (this wave's pieces: the NST - 2 younger stages may still be in flight), then everybody's; the
+      // barrier also says that every wave has finished reading tile it - 1, whose slot the next request overwrites
+      if (NST == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (NST == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_setprio(1);
+      stage(it + NST - 1);
+      const char* cA = smem + (it % NST) * D_STAGE;
+      const char* cB = cA + TILE_BYTES;
+      // all 16 fragment reads of the k-tile first, into registers of their own (a wave is alone on its SIMD: 512 registers),
+      // the 16 MFMAs behind them: the matrix pipe waits for the first k-step's reads only, the rest arrive under it
+      bf16x8 fa[4][2], fb[4][2];
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+      for (int s = 0; s < 4; ++s) {
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
+        for (int i = 0; i < 2; ++i) fa[s][i] = read_fragH<A_KS>(cA, wa * 64 + i * 32, s, lane);
 #pragma unroll
-          for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = mfma16q(fa[ti][s], fb[tj][s], acc[ti][tj]);
-      __builtin_amdgcn_s_setprio(0);
+        for (int j = 0; j < 2; ++j) fb[s][j] = read_fragH<B_KS>(cB, wb * 64 + j * 32, s, lane);
+      }
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      // ---- phase 2: a 0..63 x b 32..63
 #pragma unroll
-      for (int tj = 2; tj < 4; ++tj)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) fb[tj][s] = read_fragQ<B_KS>(cB, rowB + 16 * tj, s, lane);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_setprio(1);
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-          for (int tj = 2; tj < 4; ++tj) acc[ti][tj] = mfma16q(fa[ti][s], fb[tj][s], acc[ti][tj]);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      // ---- phase 3: a 64..127 x b 32..63
-#pragma unroll
-      for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) fa[ti][s] = read_fragQ<A_KS>(cA, 64 + 16 * ti, s, lane);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-          for (int tj = 2; tj < 4; ++tj) acc[4 + ti][tj] = mfma16q(fa[ti][s], fb[tj][s], acc[4 + ti][tj]);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      // ---- phase 4: a 64..127 x b 0..31
-      stage(1, it + 2, buf);
-      __builtin_amdgcn_s_waitcnt(0x0F74);     // vmcnt(4): everything but the B halves just issued -- A(it+1), B(it+1) landed
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-          for (int tj = 0; tj < 2; ++tj) acc[4 + ti][tj] = mfma16q(fa[ti][s], fb[tj][s], acc[4 + ti][tj]);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[s][i], fb[s][j], acc[i][j]);
     }
-    if (!wa) __builtin_amdgcn_s_barrier();    // the early group waits for the late one
-    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the trailing (unused) prefetches must not land in the epilogue's LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (zero-filling) requests must not land in the epilogue's LDS
     __builtin_amdgcn_s_barrier();
   }
-  gemm_epilogue_lds<EPI, true>(p, acc, a0 + wa * 128, b0 + wb * 64, lane, smem + wid * 16384);
+
+  if (S > 1) {
+    {   // publish this slice's partial tile: lane-contiguous 16-byte write-through stores, 4 KiB per store instruction
+      const unsigned long long q = reinterpret_cast<unsigned long long>(w.slots) + ((unsigned long long)t * S + kz) * (D_SLOT_FLOATS * 4);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(q), 0, D_SLOT_FLOATS * 4, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (((i * 2 + j) * 4 + g) * 256 + tid) * 16, 0, 16 /* sc1 */);
+          }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its stores have been written through
+    __syncthreads();
+    if (tid == 0) s_arrival = __hip_atomic_fetch_add(w.ctr + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_arrival != (unsigned)(S - 1)) return;               // not the last slice of this tile to arrive
+    f32x16 tot[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+    for (int z = 0; z < S; ++z) {                             // slice order, whoever arrived last: the sum is a function of the shape alone
+      if (z == kz) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tot[i][j][r] += acc[i][j][r];
+      } else {
+        const unsigned long long q = reinterpret_cast<unsigned long long>(w.slots) + ((unsigned long long)t * S + z) * (D_SLOT_FLOATS * 4);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(q), 0, D_SLOT_FLOATS * 4, 0x00020000);
+        u32x4 v[16];
+#pragma unroll
+        for (int n = 0; n < 16; ++n) v[n] = __builtin_amdgcn_raw_buffer_load_b128(rs, (n * 256 + tid) * 16, 0, 16 /* sc1 */);
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+          const f32x4 f = __builtin_bit_cast(f32x4, v[n]);
+          const int i = n >> 3, j = (n >> 2) & 1, g = n & 3;
+          tot[i][j][4 * g] += f[0]; tot[i][j][4 * g + 1] += f[1]; tot[i][j][4 * g + 2] += f[2]; tot[i][j][4 * g + 3] += f[3];
+        }
+      }
+    }
+    if (tid == 0) __hip_atomic_store(w.ctr + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch on this stream
+    gemm_epilogue_lds<EPI, 2>(p, tot, a0 + wa * 64, b0 + wb * 64, lane, smem + wid * 16384);
+    return;
+  }
+  gemm_epilogue_lds<EPI, 2>(p, acc, a0 + wa * 64, b0 + wb * 64, lane, smem + wid * 16384);
 }
 
-// 16x16x32 MFMAs in the 256-tile forward / dgrad kernels (octmae_set_option "gemm_mfma16"; bit 11 of the epilogue argument forces
-// the 32x32x16 kernel for tests and A/B runs)
-// Default OFF: same-process A/B of the kernels alone (tools/archive/gemm_mfma_shape_ab.py) has the 16x16x32 form 2-5 % faster on every
-// shape, but in the training step on the same box (bench.py --set gemm_mfma16=1 vs 0, three alternations) it is no faster
-// (167.5 vs 167.7 volumes/s; dgrad +3.7 % slower, forward -1 %): profiles/r04_gemm_mfma16_ab.txt.
-std::atomic<int> g_gemm_mfma16{0};
+
 // Staggered split-K slices of the 256-tile weight-gradient kernel (split_range): v = the length step between neighbouring slices in
 // 1/256 k-tiles PER OUTPUT TILE of the launch (the atomic time of a slice grows with its tile count: 256 KiB at 1.35 TB/s = 0.19 us
 // per tile against 1.7 us per k-tile, i.e. v = 29); 0 = equal slices.  octmae_set_option("wgrad_stagger", v) / OCTMAE_WGRAD_STAGGER.
@@ -1296,13 +1171,12 @@ std::atomic<int> g_gemm_mfma16{0};
 // (tools/archive/wgrad_stagger_ab.py, profiles/r04_wgrad_stagger.txt) -9 / -11 % there, and nothing or a loss for the 4- and 5-way splits
 // and for every shape at 128 volumes -- their workgroups do not end together anyway.
 std::atomic<int> g_wgrad_stagger{29};
+// The epilogue of an UNSPLIT weight-gradient launch of the phased 256-tile kernel: 0 = plain read-modify-write (one guarded load + store
+// per register), 1 = the same fire-and-forget fp32 atomics a split launch uses (still deterministic: one add per element and launch),
+// 2 = read-modify-write in batches of 16 registers through a buffer descriptor.  "wgrad_s1_atomic" / OCTMAE_WGRAD_S1_ATOMIC.
+std::atomic<int> g_wgrad_s1_atomic{2};
 
-// ---- stream-K planning (host) ----------------------------------------------------------------------------------------------
-// Workspace layout: [G slots x 256 KiB fp32 partial tiles][G flags (u32)], G = the device's CU count, caller-owned, lent per call;
-// the flags must have been zero when the workspace was first used (they hold launch generations afterwards and are never reset).
-std::atomic<unsigned> g_sk_gen{1};
-std::atomic<int> g_streamk{1};       // octmae_set_option("gemm_streamk", 0 / 1); OCTMAE_STREAMK overrides
-std::atomic<int> g_sk_launches{0};   // how many launches took the stream-K kernel (octmae_set_option("gemm_streamk_launches", any): tests)
+// CU count of the current device (cached per device)
 static int device_cus() {
   static std::atomic<int> cached[64];
   int dev = 0;
@@ -1313,87 +1187,111 @@ static int device_cus() {
   cached[dev & 63].store(v, std::memory_order_relaxed);
   return v;
 }
-static long long sk_ws_bytes_for(int G) { return (long long)G * SK_SLOT_FLOATS * 4 + (long long)G * 4; }
-// How many of the LAST tiles of an nt-tile launch go to the stream-K workgroups (0: none -- plain launch).  Taken when the last round
-// of workgroups would be between an eighth and 80 % full (a fuller one gains less than the hand-off costs; an emptier one is mostly
-// hidden already: the workgroups of a round end 40-70 us apart and the stragglers' CUs take the few extra tiles), or when the whole
-// launch has fewer tiles than CUs (small batches) and every workgroup still gets >= 4 k-tiles.
-static int sk_plan(int nt, int ktiles, int G, int* G_eff) {
-  static const int env = getenv("OCTMAE_STREAMK") ? atoi(getenv("OCTMAE_STREAMK")) : -1;
-  const int on = env >= 0 ? env : g_streamk.load(std::memory_order_relaxed);
-  *G_eff = G;
-  if (!on || ktiles < 4) return 0;
-  if (nt >= G) {
-    const int rem = nt % G;
-    // every stream-K workgroup gets >= 4 k-tiles (an empty span would publish nothing and its owner would wait for ever)
-    long long g = (long long)rem * ktiles / 4;
-    if (g > G) g = G;
-    *G_eff = (int)g;
-    if (g < 2LL * rem) return 0;                           // would not even double the fill of that round
-    if (on == 2) return rem;                               // 2: whenever there is a partial round (measurement)
-    return (rem * 8 >= G && rem * 10 <= G * 8) ? rem : 0;
-  }
-  // Fewer tiles than CUs (1-4 volumes per step: the reference's shipped recipe runs ONE volume per GPU).  Every launch then costs one
-  // tile time whatever its size; only the longest k-loops are worth splitting: each tile into 4 EQUAL parts of >= 12 k-tiles (one
-  // owner + 3 peers: K >= 3072, i.e. fc2 forward and the fc1 / qkv dgrads of the encoder).  Measured (profiles/r05_streamk_ab.txt):
-  // -9 ... -19 % on those launches at one volume; a 2-way split of K = 2048 loses 20-40 % (publish + gather cost ~15 us, more than
-  // half a k-loop), a 10-way split 40-190 % (one CU gathering ten 256 KiB partials).
-  if (4LL * nt <= G && ktiles / 4 >= 12) {
-    *G_eff = 4 * nt;
-    return nt;
-  }
-  return 0;
-}
-
-template <bool A_KS, bool B_KS, int EPI>
-static int launch256_sk(const GemmParams& p, hipStream_t st, void* ws, long long ws_bytes, bool* taken) {
-  *taken = false;
-  const int nt = p.tiles_a * p.tiles_b, G = device_cus();
-  int Ge = G;
-  const int skt = (ws && ws_bytes >= sk_ws_bytes_for(G) && (p.NA & 7) == 0) ? sk_plan(nt, p.ktiles, G, &Ge) : 0;
-  if (skt <= 0) return 0;
-  SkLaunch s;
-  s.G = Ge; s.sk_tiles = skt; s.nt_dp = nt - skt;
-  s.slots = reinterpret_cast<float*>(ws);
-  s.flags = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + (long long)G * SK_SLOT_FLOATS * 4);
-  s.gen = g_sk_gen.fetch_add(1, std::memory_order_relaxed);
-  if (s.gen == 0) s.gen = g_sk_gen.fetch_add(1, std::memory_order_relaxed);     // 0 is the initial content of the flags
-  auto kern = gemm256p_sk_kernel<A_KS, B_KS, EPI>;
-  static DynLdsOnce once;
-  if (int rc = once.ensure(reinterpret_cast<const void*>(kern), 4 * TILE2_BYTES)) return rc;
-  hipLaunchKernelGGL(kern, dim3(Ge + s.nt_dp, 1, 1), dim3(512), 4 * TILE2_BYTES, st, p, s);
-  OCTMAE_LAUNCH_CHECK();
-  *taken = true;
-  g_sk_launches.fetch_add(1, std::memory_order_relaxed);
-  return 0;
-}
 
 template <bool A_KS, bool B_KS, int EPI, bool OUT_AB>
-static int launch256(const GemmParams& p, int splitk, hipStream_t st, bool phased, bool mfma16, void* sk_ws = nullptr,
-                     long long sk_bytes = 0) {
-  if constexpr (!OUT_AB && !(A_KS && B_KS)) {
-    if (phased && !mfma16 && splitk == 1 && sk_ws != nullptr) {
-      bool taken = false;
-      if (int rc = launch256_sk<A_KS, B_KS, EPI>(p, st, sk_ws, sk_bytes, &taken)) return rc;
-      if (taken) return 0;
-    }
-  }
-  if constexpr (!OUT_AB && !(A_KS && B_KS)) {
-    if (mfma16 && phased && splitk == 1 && (p.NA & 7) == 0) {
-      auto kq = gemm256q_kernel<A_KS, B_KS, EPI>;
-      static DynLdsOnce onceq;
-      if (int rc = onceq.ensure(reinterpret_cast<const void*>(kq), 4 * TILE2_BYTES)) return rc;
-      hipLaunchKernelGGL(kq, dim3(p.tiles_a * p.tiles_b, 1, 1), dim3(512), 4 * TILE2_BYTES, st, p);
-      OCTMAE_LAUNCH_CHECK();
-      return 0;
-    }
-  }
+static int launch256(const GemmParams& p, int splitk, hipStream_t st, bool phased) {
   auto kern = phased ? gemm256p_kernel<A_KS, B_KS, EPI, OUT_AB> : gemm256_kernel<A_KS, B_KS, EPI, OUT_AB>;
   static DynLdsOnce once[2];
   if (int rc = once[phased].ensure(reinterpret_cast<const void*>(kern), 4 * TILE2_BYTES)) return rc;
   dim3 grid(p.tiles_a * p.tiles_b, 1, splitk);
   hipLaunchKernelGGL(kern, grid, dim3(512), 4 * TILE2_BYTES, st, p);
   OCTMAE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- the small-launch kernel: workspace, plan, launch -------------------------------------------------------------------------
+// Workspace (caller-owned, lent per call, one per stream): [D_WS_SLOTS partial tiles of 64 KiB][D_WS_TILES arrival counters].  The
+// counters must be zero when the workspace is first lent; every launch leaves them zero.
+constexpr int D_WS_SLOTS = 1024, D_WS_TILES = 4096;
+static long long d_ws_bytes() { return (long long)D_WS_SLOTS * D_SLOT_FLOATS * 4 + (long long)D_WS_TILES * 4; }
+
+std::atomic<int> g_gemm_small{1};          // octmae_set_option("gemm_small", 0 / 1); OCTMAE_GEMM_SMALL overrides
+std::atomic<int> g_small_launches{0};      // how many launches took gemm128d_kernel ("gemm_small_launches": tests)
+std::atomic<int> g_small_split_launches{0};
+
+struct Plan128 {
+  int use;      // 1: gemm128d_kernel
+  int S;        // k slices per tile (1: no workspace needed)
+  int nst;      // ring stages: 4 (one workgroup per CU) or 2 (two)
+};
+// Which kernel a forward / dgrad launch of NA x NB x K takes on G CUs (fitted on MI355X with tools/gemm_small_fit.py: device times of
+// graph-replayed launches, profiles/r06_gemm_small_fit.txt).
+//  * At most one round of 256-tiles (nt256 <= G, the regime the kernel was built for): a latency model in microseconds.  A workgroup of
+//    the 256-tile kernel takes ~1.05 us per k-tile + ~6.5 us (prologue, epilogue, launch); one of this kernel ~0.5 us per k-tile + ~4.5 us
+//    alone on its CU (4-stage ring) and ~0.85 us per k-tile + ~5.5 us in rounds of two per CU (2-stage ring); a k split adds the publish
+//    and the last arriver's gather, ~5.5 us + ~1.5 us per slice beyond the second.
+//  * More than one round: both kernels stream, and what differs is how much of their LAST round is empty.  Per 128 x 128 x 64 block of
+//    work the 256-tile kernel costs 1.18 / 4 us and this kernel's 2-stage form 0.64 / 2 us; with eff = tiles / (rounds x slots) of each
+//    (slots: G and 2 G) it is taken when 0.32 / eff128 < 0.9 x 0.295 / eff256 -- e.g. the decoder's [8 x 5121 rows] x K -> 512 dgrads:
+//    322 tiles of 256 = 1.26 rounds of CUs against 1284 of 128 = 2.5 rounds of 512 slots, 82 against 96 us.  The 128-volume shapes of
+//    the headline step sit at eff256 >= 0.83 and keep the 256-tile kernel (tests/test_cpu_host.py).
+static Plan128 plan128(int NA, int NB, int K, int G, bool have_ws, bool big256_ok) {
+  static const int env = getenv("OCTMAE_GEMM_SMALL") ? atoi(getenv("OCTMAE_GEMM_SMALL")) : -1;
+  const int on = env >= 0 ? env : g_gemm_small.load(std::memory_order_relaxed);
+  Plan128 pl{0, 1, 4};
+  if (!on) return pl;
+  const int ktiles = (K + TK - 1) / TK;
+  const long long nt128 = (long long)((NA + T1 - 1) / T1) * ((NB + T1 - 1) / T1);
+  const long long nt256 = (long long)((NA + T2 - 1) / T2) * ((NB + T2 - 1) / T2);
+  if (big256_ok && nt256 > G) {
+    const double eff256 = (double)nt256 / (double)(((nt256 + G - 1) / G) * G);
+    const double eff128 = (double)nt128 / (double)(((nt128 + 2 * G - 1) / (2 * G)) * 2 * G);
+    if (0.32 / eff128 < 0.9 * 0.295 / eff256) { pl.use = 1; pl.S = 1; pl.nst = 2; }
+    return pl;
+  }
+  const double t256 = big256_ok ? 1.05 * ktiles + 6.5 : 1e30;
+  double best = 1e30;
+  for (int S = 1; S <= 4; ++S) {
+    if (S > 1 && (!have_ws || ktiles / S < 8 || nt128 * S > D_WS_SLOTS || nt128 > D_WS_TILES)) break;
+    const int kper = (ktiles + S - 1) / S;
+    if (S > 1 && (long long)(S - 1) * kper >= ktiles) continue;          // an empty last slice
+    const long long wg = nt128 * S;
+    const double split = S > 1 ? 5.5 + 1.5 * (S - 2) : 0.0;
+    const double t4 = (double)((wg + G - 1) / G) * (0.5 * kper + 4.5 + split);
+    const double t2 = wg > G ? (double)((wg + 2 * G - 1) / (2 * G)) * (0.85 * kper + 5.5 + split) : 1e30;
+    if (t4 < best) { best = t4; pl.S = S; pl.nst = 4; }
+    if (t2 < best) { best = t2; pl.S = S; pl.nst = 2; }
+  }
+  pl.use = best < 0.92 * t256;
+  if (!pl.use) { pl.S = 1; pl.nst = 4; }
+  return pl;
+}
+
+// operands the small-launch kernel can take (the epilogue transposes 8-column chunks; LDS-DMA of whole k-tiles; 32-bit buffer ranges)
+static bool gemm128_ok(int NA, int NB, int K, int lda, int ldb, bool a_ks, bool b_ks) {
+  if ((NA & 7) != 0 || (a_ks && b_ks)) return false;
+  if ((!a_ks || !b_ks) && (K % TK) != 0) return false;
+  const size_t a_bytes = (size_t)(a_ks ? K : NA) * lda * 2, b_bytes = (size_t)(b_ks ? K : NB) * ldb * 2;
+  return a_bytes < 0xFFF00000ull && b_bytes < 0xFFF00000ull;
+}
+
+template <bool A_KS, bool B_KS, int EPI>
+static int launch128d(GemmParams p, const Plan128& pl, void* ws, hipStream_t st) {
+  p.tiles_a = (p.NA + T1 - 1) / T1;
+  p.tiles_b = (p.NB + T1 - 1) / T1;
+  p.cgroup = p.tiles_a;
+  p.kstagger = 0;
+  p.ktiles_per_split = (p.ktiles + pl.S - 1) / pl.S;
+  SplitWs w{nullptr, nullptr};
+  if (pl.S > 1) {
+    w.slots = reinterpret_cast<float*>(ws);
+    w.ctr = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + (long long)D_WS_SLOTS * D_SLOT_FLOATS * 4);
+    g_small_split_launches.fetch_add(1, std::memory_order_relaxed);
+  }
+  const int nt = p.tiles_a * p.tiles_b;
+  if (pl.nst == 2) {
+    auto kern = gemm128d_kernel<A_KS, B_KS, EPI, 2>;
+    static DynLdsOnce once;
+    if (int rc = once.ensure(reinterpret_cast<const void*>(kern), 2 * D_STAGE)) return rc;
+    hipLaunchKernelGGL(kern, dim3(nt * pl.S, 1, 1), dim3(256), 2 * D_STAGE, st, p, w, pl.S);
+  } else {
+    auto kern = gemm128d_kernel<A_KS, B_KS, EPI, 4>;
+    static DynLdsOnce once;
+    if (int rc = once.ensure(reinterpret_cast<const void*>(kern), 4 * D_STAGE)) return rc;
+    hipLaunchKernelGGL(kern, dim3(nt * pl.S, 1, 1), dim3(256), 4 * D_STAGE, st, p, w, pl.S);
+  }
+  OCTMAE_LAUNCH_CHECK();
+  g_small_launches.fetch_add(1, std::memory_order_relaxed);
   return 0;
 }
 
@@ -1425,22 +1323,30 @@ static int wgrad_stagger_for(int ktiles, int splitk, int tiles) {
   return d > 0 ? (int)d : 0;
 }
 
+static int wgrad_s1_atomic() {
+  static const int env = getenv("OCTMAE_WGRAD_S1_ATOMIC") ? atoi(getenv("OCTMAE_WGRAD_S1_ATOMIC")) : -1;
+  return env >= 0 ? env : g_wgrad_s1_atomic.load(std::memory_order_relaxed);
+}
+
 extern "C" int octmae_colsum_accum(const void* in, int in_is_bf16, float* out, int M, int N, int ld, void* stream);
 
 // C[b][a] (+epilogue) = sum_k A[a][k] B[b][k];  see include/octmae.h for the contract.
 static int gemm_impl(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
                      int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided,
                      int b_kstrided, int epilogue, int splitk, void* stream, const float* rowscale, int rows_per_scale,
-                     float* colsum_ws = nullptr, void* sk_ws = nullptr, long long sk_bytes = 0) {
-  // bit 8 of `epilogue` forces the 128-tile kernel, bit 9 the two-stage (un-phased) 256-tile main loop: tests and A/B runs
-  // exercise every kernel on the same problem
+                     float* colsum_ws = nullptr, void* split_ws = nullptr, long long split_bytes = 0) {
+  // Variant bits of `epilogue` (tests and A/B runs exercise every kernel on the same problem): bit 8 forces the 128-tile
+  // register-staged kernel, bit 9 the two-stage (un-phased) 256-tile main loop, bit 10 the phased one; bit 12 / 13 force the
+  // small-launch kernel gemm128d_kernel with a 4- / 2-stage ring (its k split is then `splitk`, 1 .. 4, which otherwise only the
+  // weight gradients read); bit 14 forbids it (the pre-round-6 choice); bits 16-18: the forced kernel's k split where the entry point has no `splitk`.
   const int variant = (epilogue >> 8) & 1;
+  const int force128 = ((epilogue >> 12) & 1) ? 4 : ((epilogue >> 13) & 1) ? 2 : 0;
+  const bool never128 = ((epilogue >> 14) & 1) != 0;
   // phased main loop by default (dgrad, wgrad: +10..25 % over the two-stage loop; forward, re-measured in round 2 after the
   // epilogue work: qkv -4 %, proj -11 %, fc2 -8 %, fc1 + GELU -1.5 %, decoder fc1 + GELU +0.6 % -- in round 1 the two-stage loop
-  // had still been 12 % faster at K = 1024).  bit 9 forces the two-stage loop, bit 10 the phased one.
+  // had still been 12 % faster at K = 1024).
   const bool phased = ((epilogue >> 10) & 1) ? true : ((epilogue >> 9) & 1) ? false : true;
-  static const int env16 = getenv("OCTMAE_GEMM_MFMA16") ? atoi(getenv("OCTMAE_GEMM_MFMA16")) : -1;      // same-box A/B of whole steps
-  const bool mfma16 = ((epilogue >> 11) & 1) ? false : env16 >= 0 ? env16 != 0 : (g_gemm_mfma16.load(std::memory_order_relaxed) != 0);
+  const int forced_split = ((epilogue >> 16) & 7) ? ((epilogue >> 16) & 7) : splitk;     // bits 16-18: the forced kernel's k split
   epilogue &= 0xff;
   OCTMAE_CHECK_ARG(A && B && C);
   OCTMAE_CHECK_ARG(NA > 0 && NB > 0 && K > 0);
@@ -1497,18 +1403,40 @@ static int gemm_impl(const void* A, const void* B, void* C, void* C2, const floa
   p.ktiles_per_split = (p.ktiles + splitk - 1) / splitk;
   splitk = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
 
+  // The small-launch kernel (forward / dgrad kinds): when the cost model says so (plan128), or forced.
+  Plan128 pl{0, 1, 4};
+  if (epilogue != EPI_ACCUM && !never128 && (variant & 1) == 0 && gemm128_ok(NA, NB, K, lda, ldb, a_kstrided != 0, b_kstrided != 0)) {
+    const bool have_ws = split_ws != nullptr && split_bytes >= d_ws_bytes();
+    if (force128) {
+      pl.use = 1; pl.nst = force128;
+      pl.S = forced_split < 1 ? 1 : forced_split > 4 ? 4 : forced_split;
+      while (pl.S > 1 && (!have_ws || (long long)(pl.S - 1) * ((p.ktiles + pl.S - 1) / pl.S) >= p.ktiles ||
+                          (long long)((NA + T1 - 1) / T1) * ((NB + T1 - 1) / T1) * pl.S > D_WS_SLOTS)) --pl.S;
+    } else if (!((epilogue >> 9) & 1) && !((epilogue >> 10) & 1)) {
+      pl = plan128(NA, NB, K, device_cus(), have_ws, big);
+    }
+  }
+
   // EPI_DGELU with C2: C2 is an fp32 [NA] vector that receives += the column sums of C (bias gradient of the Linear whose
-  // activation is being differentiated).  Fused into the 256-tile epilogue; the 128-tile kernel is followed by the
-  // stand-alone column-sum kernel.
+  // activation is being differentiated).  Fused into the LDS-transposing epilogues (256-tile kernels, small-launch kernel); the
+  // 128-tile register-staged kernel is followed by the stand-alone column-sum kernel.
   float* dgelu_colsum = (epilogue == EPI_DGELU) ? reinterpret_cast<float*>(C2) : nullptr;
-  if (epilogue == EPI_DGELU && !(big && (NA & 7) == 0)) p.C2 = nullptr;
+  if (epilogue == EPI_DGELU && !((big || pl.use) && (NA & 7) == 0)) p.C2 = nullptr;
   p.ldc2 = 0; p.hd = 0;
   p.kstagger = (big && epilogue == EPI_ACCUM) ? wgrad_stagger_for(p.ktiles, splitk, p.tiles_a * p.tiles_b) : 0;
-  const int ws_rows = 4 * p.tiles_b;             // 64-row slabs of the 256-tile grid
+  p.atomic1 = (big && phased && epilogue == EPI_ACCUM) ? wgrad_s1_atomic() : 0;
+  // 64-row slabs that write a row of partial column sums: those of the grid that runs (octmae_dgelu_colsum_ws_rows covers both)
+  const int ws_rows = pl.use ? 2 * ((NB + T1 - 1) / T1) : 4 * p.tiles_b;
   if (epilogue == EPI_DGELU && p.C2 != nullptr && colsum_ws != nullptr) { p.C2 = colsum_ws; p.ldc2 = NA; }
 #define OCTMAE_GEMM_CASE(AKS, BKS, E, AB)                                  \
   if (a_kstrided == AKS && b_kstrided == BKS && epilogue == E) {           \
-    int rc_ = big ? launch256<AKS, BKS, E, AB>(p, splitk, st, phased, mfma16, sk_ws, sk_bytes) : launch<AKS, BKS, E, AB>(p, splitk, st);  \
+    int rc_;                                                               \
+    if constexpr (!AB) {                                                   \
+      rc_ = pl.use ? launch128d<AKS, BKS, E>(p, pl, split_ws, st)          \
+                   : big ? launch256<AKS, BKS, E, AB>(p, splitk, st, phased) : launch<AKS, BKS, E, AB>(p, splitk, st);  \
+    } else {                                                               \
+      rc_ = big ? launch256<AKS, BKS, E, AB>(p, splitk, st, phased) : launch<AKS, BKS, E, AB>(p, splitk, st);           \
+    }                                                                      \
     if (rc_ == 0 && E == EPI_DGELU && dgelu_colsum != nullptr && p.C2 == nullptr)                                       \
       rc_ = octmae_colsum_accum(C, 1, dgelu_colsum, NB, NA, ldc, stream);                                                \
     if (rc_ == 0 && E == EPI_DGELU && dgelu_colsum != nullptr && p.ldc2 > 0)                                             \
@@ -1583,6 +1511,7 @@ extern "C" int octmae_wgrad_accum_pair(const void* dY0, const void* X0, float* g
       p.cgroup = c;
     }
     p.ldc2 = 0; p.hd = 0; p.kstagger = 0;
+    p.atomic1 = wgrad_s1_atomic();
     return true;
   };
   if (!fill(pp.p0, dY0, X0, gW0, gB0, N0, K0, ldy0, ldx0, ldw0) || !fill(pp.p1, dY1, X1, gW1, gB1, N1, K1, ldy1, ldx1, ldw1)) return -2;
@@ -1610,45 +1539,46 @@ extern "C" int octmae_gemm_bf16(const void* A, const void* B, void* C, void* C2,
                    nullptr, 1);
 }
 
-// The stream-K plan of a launch with `nt` output tiles of `ktiles` k-tiles on `cus` CUs under the current "gemm_streamk" option (host-side
-// arithmetic only, no GPU is touched): returns the number of tiles handed to the stream-K workgroups (0 = plain launch) and writes the
-// number of those workgroups to *g_eff.  For tests of the planning code: every stream-K workgroup must get a NON-EMPTY span (an empty
-// one would never publish, and the owner of its tile would wait for ever).
-extern "C" int octmae_gemm_streamk_plan(int nt, int ktiles, int cus, int* g_eff) {
-  OCTMAE_CHECK_ARG(nt > 0 && ktiles > 0 && cus > 0 && g_eff);
-  return sk_plan(nt, ktiles, cus, g_eff);
+// Which kernel a forward / dgrad launch of NA x NB x K would take on `cus` CUs under the current "gemm_small" option (host-side
+// arithmetic only, no GPU is touched; for tests of the planning code): returns 1 for the small-launch kernel (gemm128d_kernel) and
+// writes its k split to *slices and its ring depth to *stages, 0 for the 256-tile / register-staged kernels.  `have_ws`: a split
+// workspace is lent; `big_ok`: the problem qualifies for the 256-tile kernel.
+extern "C" int octmae_gemm_small_plan(int NA, int NB, int K, int cus, int have_ws, int big_ok, int* slices, int* stages) {
+  OCTMAE_CHECK_ARG(NA > 0 && NB > 0 && K > 0 && cus > 0 && slices && stages);
+  const Plan128 pl = plan128(NA, NB, K, cus, have_ws != 0, big_ok != 0);
+  *slices = pl.S; *stages = pl.nst;
+  return pl.use;
 }
 
-extern "C" int octmae_gemm_streamk_ws_kib(void) { return (int)((sk_ws_bytes_for(device_cus()) + 1023) / 1024); }
+extern "C" int octmae_gemm_split_ws_kib(void) { return (int)((d_ws_bytes() + 1023) / 1024); }
 
 extern "C" int octmae_gemm_bf16_ws(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
                                    int NA, int NB, int K, int lda, int ldb, int ldc, int ldaux, int a_kstrided,
-                                   int b_kstrided, int epilogue, int splitk, void* sk_ws, long long sk_ws_bytes, void* stream) {
+                                   int b_kstrided, int epilogue, int splitk, void* split_ws, long long split_ws_bytes, void* stream) {
   return gemm_impl(A, B, C, C2, bias, aux, NA, NB, K, lda, ldb, ldc, ldaux, a_kstrided, b_kstrided, epilogue, splitk, stream,
-                   nullptr, 1, nullptr, sk_ws, sk_ws_bytes);
+                   nullptr, 1, nullptr, split_ws, split_ws_bytes);
 }
 
 extern "C" int octmae_linear_resid_rowscale(const void* W, const void* X, float* out, const float* bias, const float* res,
                                             const float* rowscale, int rows_per_scale, int N, int M, int K, int ldw, int ldx,
-                                            int ldout, int ldres, int small_tile, void* sk_ws, long long sk_ws_bytes, void* stream) {
+                                            int ldout, int ldres, int variant, void* split_ws, long long split_ws_bytes, void* stream) {
   OCTMAE_CHECK_ARG(rowscale != nullptr && rows_per_scale > 0);
-  return gemm_impl(W, X, out, nullptr, bias, res, N, M, K, ldw, ldx, ldout, ldres, 0, 0, EPI_RESID | (small_tile & 0xF00), 1,
-                   stream, rowscale, rows_per_scale, nullptr, sk_ws, sk_ws_bytes);
+  return gemm_impl(W, X, out, nullptr, bias, res, N, M, K, ldw, ldx, ldout, ldres, 0, 0, EPI_RESID | (variant & 0x77F00), 1,
+                   stream, rowscale, rows_per_scale, nullptr, split_ws, split_ws_bytes);
 }
 
 // dX[M][K] bf16 = dY[M][N] @ W[N][K]  and  delta[M][H] f32 = -sum over each head's hd columns of dX * O  (O bf16 [M][K], K = H * hd):
 // the proj dgrad of an attention block, whose output dO the attention backward multiplies with O row by row anyway.
-// Returns -2 when the problem does not take the 256-tile kernel (the caller then uses octmae_gemm_bf16 + octmae_attn_bwd_fused).
+// Returns -2 when the problem takes neither LDS-transposing kernel (the caller then uses octmae_gemm_bf16 + octmae_attn_bwd_fused).
 extern "C" int octmae_linear_dgrad_delta(const void* W, const void* dY, void* dX, const void* O, float* delta, int M, int N, int K,
-                                         int ldw, int ldy, int ldx, int ldo, int H, int hd, int variant, void* sk_ws,
-                                         long long sk_ws_bytes, void* stream) {
+                                         int ldw, int ldy, int ldx, int ldo, int H, int hd, int variant, void* split_ws,
+                                         long long split_ws_bytes, void* stream) {
   OCTMAE_CHECK_ARG(W && dY && dX && O && delta && M > 0 && N > 0 && K > 0);
   OCTMAE_CHECK_ARG((hd == 32 || hd == 64) && H > 0 && H * hd == K && (ldw % 8) == 0 && (ldy % 8) == 0 && (ldx % 4) == 0 && (ldo % 4) == 0);
   OCTMAE_CHECK_ARG(K % 8 == 0 && N % 8 == 0);
   const size_t a_bytes = (size_t)N * ldw * 2, b_bytes = (size_t)M * ldy * 2;
   const bool big = K >= T2 && M >= T2 && a_bytes < 0xFFF00000ull && b_bytes < 0xFFF00000ull && ((variant >> 8) & 1) == 0 &&
                    (N % TK) == 0 && (K & 7) == 0;
-  if (!big) return -2;
   GemmParams p;
   p.A = reinterpret_cast<const bf16_t*>(W); p.B = reinterpret_cast<const bf16_t*>(dY);
   p.C = dX; p.C2 = delta; p.bias = nullptr; p.aux = O; p.rowscale = nullptr; p.rows_per_scale = 1;
@@ -1659,11 +1589,23 @@ extern "C" int octmae_linear_dgrad_delta(const void* W, const void* dY, void* dX
   if (p.tiles_a >= 16 && p.tiles_a % 4 == 0 && 4 * (size_t)T2 * N * 2 <= (2u << 20)) p.cgroup = 4;
   p.hd = hd; p.ldc2 = H; p.kstagger = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (sk_ws != nullptr) {
-    bool taken = false;
-    if (int rc = launch256_sk<true, false, EPI_DELTA>(p, st, sk_ws, sk_ws_bytes, &taken)) return rc;
-    if (taken) return 0;
+  const int force128 = ((variant >> 12) & 1) ? 4 : ((variant >> 13) & 1) ? 2 : 0;
+  if (((variant >> 8) & 1) == 0 && ((variant >> 14) & 1) == 0 && gemm128_ok(K, M, N, ldw, ldy, true, false)) {
+    const bool have_ws = split_ws != nullptr && split_ws_bytes >= d_ws_bytes();
+    Plan128 pl{0, 1, 4};
+    if (force128) {
+      pl.use = 1; pl.nst = force128;
+      pl.S = (variant >> 16) & 7;
+      if (pl.S < 1) pl.S = 1;
+      if (pl.S > 4) pl.S = 4;
+      while (pl.S > 1 && (!have_ws || (long long)(pl.S - 1) * ((p.ktiles + pl.S - 1) / pl.S) >= p.ktiles ||
+                          (long long)((K + T1 - 1) / T1) * ((M + T1 - 1) / T1) * pl.S > D_WS_SLOTS)) --pl.S;
+    } else {
+      pl = plan128(K, M, N, device_cus(), have_ws, big);
+    }
+    if (pl.use) return launch128d<true, false, EPI_DELTA>(p, pl, split_ws, st);
   }
+  if (!big) return -2;
   auto kern = gemm256p_kernel<true, false, EPI_DELTA, false>;
   static DynLdsOnce once;
   if (int rc = once.ensure(reinterpret_cast<const void*>(kern), 4 * TILE2_BYTES)) return rc;
@@ -1675,9 +1617,9 @@ extern "C" int octmae_linear_dgrad_delta(const void* W, const void* dY, void* dX
 extern "C" int octmae_dgelu_colsum_ws_rows(int M) { return M > 0 ? 4 * ((M + T2 - 1) / T2) : 0; }
 
 extern "C" int octmae_linear_dgrad_dgelu(const void* W, const void* dY, void* dX, const void* pre, float* ws, float* bias_grad,
-                                         int M, int N, int K, int ldw, int ldy, int ldx, int ldpre, int small_tile, void* sk_ws,
-                                         long long sk_ws_bytes, void* stream) {
+                                         int M, int N, int K, int ldw, int ldy, int ldx, int ldpre, int variant, void* split_ws,
+                                         long long split_ws_bytes, void* stream) {
   OCTMAE_CHECK_ARG(bias_grad == nullptr || ws != nullptr);
-  return gemm_impl(W, dY, dX, bias_grad, nullptr, pre, K, M, N, ldw, ldy, ldx, ldpre, 1, 0, EPI_DGELU | (small_tile & 0xF00), 1, stream, nullptr, 1,
-                   bias_grad != nullptr ? ws : nullptr, sk_ws, sk_ws_bytes);
+  return gemm_impl(W, dY, dX, bias_grad, nullptr, pre, K, M, N, ldw, ldy, ldx, ldpre, 1, 0, EPI_DGELU | (variant & 0x77F00), 1, stream, nullptr, 1,
+                   bias_grad != nullptr ? ws : nullptr, split_ws, split_ws_bytes);
 }

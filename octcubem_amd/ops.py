@@ -188,44 +188,44 @@ _GEMM_KIND = {(0, 0): "gemm_fwd", (1, 0): "gemm_dgrad", (1, 1): "gemm_wgrad"}
 FORCE_SMALL_TILE = False    # tests: route every GEMM through the 128-tile register-staged kernel
 FORCE_TWO_STAGE = False     # tests / A-B: the un-phased two-stage main loop of the 256-tile kernel
 FORCE_PHASED = False        # tests / A-B: the phased main loop also where the two-stage one is the default
-FORCE_MFMA32 = False        # tests / A-B: never the 16x16x32 kernel (gemm256q_kernel; selected by set_option("gemm_mfma16", 1))
+FORCE_SMALL_LAUNCH = 0      # tests / A-B: 4 or 2 = every forward / dgrad GEMM through gemm128d_kernel with that ring depth (its k split:
+FORCE_SPLITK = 1            #   FORCE_SPLITK, 1 .. 4); -1 = never that kernel (the pre-round-6 choice)
 
 
 def _variant_bits():
     return (0x100 if FORCE_SMALL_TILE else 0) | (0x200 if FORCE_TWO_STAGE else 0) | (0x400 if FORCE_PHASED else 0) | \
-        (0x800 if FORCE_MFMA32 else 0)
+        (0x1000 if FORCE_SMALL_LAUNCH == 4 else 0x2000 if FORCE_SMALL_LAUNCH == 2 else 0x4000 if FORCE_SMALL_LAUNCH < 0 else 0) | \
+        (((FORCE_SPLITK & 7) << 16) if FORCE_SMALL_LAUNCH > 0 else 0)
 
 
-# Stream-K workspace of the forward / dgrad GEMMs (octmae_gemm_bf16_ws): one per (device, stream) -- launches on one stream run one
-# after the other and may share it, launches on different streams may not.  64 MiB of partial-tile slots + one flag per CU, zeroed
-# once (the flags then hold launch generations).  OFF by default: built, parity-green and race-free (tests/test_gpu_streamk.py), and
-# measured to buy nothing -- the 2.52-round GEMMs of a 32-volume rank already run their half-empty last round 1.6 x faster per
-# tile (the step is power-bound: idle CUs hand their watts to the busy ones), 202.1 vs 202.8 ms per 32-volume step; below one round
-# of tiles the gather of many 256 KiB partials by one CU costs more than the idle CUs (profiles/r05_streamk_ab.txt, DESIGN.md
-# section 4).  bench.py --set ops.STREAMK=1 / OCTMAE_STREAMK_WS=1 lends the workspace.
-STREAMK = os.environ.get("OCTMAE_STREAMK_WS", "0") == "1"
-_sk_ws = {}
+# Split-K workspace of the small-launch forward / dgrad kernel (octmae_gemm_bf16_ws): one per (device, stream) -- launches on one
+# stream run one after the other and may share it, launches on different streams may not.  64 MiB of partial-tile slots + 16 KiB of
+# arrival counters, zeroed once (every launch leaves the counters zero).  ON by default since round 6: a long reduction on few
+# tiles (the fc2 forward of ONE volume: 88 tiles of 128 x 128, K = 4096) is split 2-4 ways, deterministically (csrc/gemm.hip,
+# gemm128d_kernel).  OCTMAE_SPLIT_WS=0 / bench.py --set ops.SPLIT_WS=0: never lend it (no launch is split).
+SPLIT_WS = os.environ.get("OCTMAE_SPLIT_WS", "1") != "0"
+_split_ws = {}
 
 
-def _streamk_ws(st: int):
+def _split_ws_for(st: int):
     """(pointer, bytes) of the current device's workspace for stream handle `st`, or (None, 0)."""
-    if not STREAMK:
+    if not SPLIT_WS:
         return None, 0
     key = (torch.cuda.current_device(), st)
-    ws = _sk_ws.get(key)
+    ws = _split_ws.get(key)
     if ws is None:
-        if len(_sk_ws) >= 8:                        # a process that keeps creating streams: do not hoard 64 MiB for each
-            _sk_ws.clear()
-        ws = _sk_ws[key] = torch.zeros(load().octmae_gemm_streamk_ws_kib() * 1024, dtype=torch.uint8, device="cuda")
+        if len(_split_ws) >= 8:                     # a process that keeps creating streams: do not hoard 64 MiB for each
+            _split_ws.clear()
+        ws = _split_ws[key] = torch.zeros(load().octmae_gemm_split_ws_kib() * 1024, dtype=torch.uint8, device="cuda")
     return ws.data_ptr(), ws.numel()
 
 
 def _gemm(A, B, C, NA, NB, K, lda, ldb, ldc, a_ks, b_ks, epi, C2=None, bias=None, aux=None, ldaux=0, splitk=1):
     st = _stream()
-    if epi != EPI_ACCUM and not FORCE_SMALL_TILE:   # forward / dgrad kinds: lend the stream-K workspace
-        skp, skn = _streamk_ws(st)
+    if epi != EPI_ACCUM and not FORCE_SMALL_TILE:   # forward / dgrad kinds: lend the split-K workspace
+        skp, skn = _split_ws_for(st)
         args = (A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(C2), _p(bias), _p(aux), NA, NB, K, lda, ldb, ldc, ldaux, a_ks, b_ks,
-                epi | _variant_bits(), splitk, skp, skn, st)
+                epi | _variant_bits(), FORCE_SPLITK if FORCE_SMALL_LAUNCH > 0 else splitk, skp, skn, st)
         fn = "octmae_gemm_bf16_ws"
     else:
         args = (A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(C2), _p(bias), _p(aux), NA, NB, K, lda, ldb, ldc, ldaux, a_ks, b_ks,
@@ -257,7 +257,7 @@ def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], m
         out = torch.empty((M, N), dtype=F32, device=dev)
         st = _stream()
         args = (w.data_ptr(), x.data_ptr(), out.data_ptr(), _p(bias), res.data_ptr(), rowscale.data_ptr(), rows_per_scale, N, M, K,
-                w.stride(0), x.stride(0), N, res.stride(0), _variant_bits(), *_streamk_ws(st), st)
+                w.stride(0), x.stride(0), N, res.stride(0), _variant_bits(), *_split_ws_for(st), st)
         _launch(f"gemm_fwd_epi{EPI_RESID}", 2.0 * N * M * K, 2.0 * (N * K + M * K) + 8.0 * N * M,
                 lambda: call("octmae_linear_resid_rowscale", *args))
         return out
@@ -300,7 +300,7 @@ def linear_dgrad(dy: torch.Tensor, w: torch.Tensor, pre: Optional[torch.Tensor] 
         ws = torch.empty((rows, K), dtype=F32, device=dy.device)
         st = _stream()
         args = (w.data_ptr(), dy.data_ptr(), dx.data_ptr(), pre.data_ptr(), ws.data_ptr(), colsum.data_ptr(), M, N, K, w.stride(0),
-                dy.stride(0), K, pre.stride(0), _variant_bits(), *_streamk_ws(st), st)
+                dy.stride(0), K, pre.stride(0), _variant_bits(), *_split_ws_for(st), st)
         if KTIMER is None:
             call("octmae_linear_dgrad_dgelu", *args)
         else:   # two launches (GEMM + the fold of the partial sums), timed together
@@ -325,7 +325,7 @@ def linear_dgrad_delta(dy: torch.Tensor, w: torch.Tensor, o: torch.Tensor, H: in
     delta = torch.empty((M, H), dtype=F32, device=dy.device)
     st = _stream()
     args = (w.data_ptr(), dy.data_ptr(), dx.data_ptr(), o.data_ptr(), delta.data_ptr(), M, N, K, w.stride(0), dy.stride(0), K, o.stride(0),
-            H, HD, _variant_bits(), *_streamk_ws(st), st)
+            H, HD, _variant_bits(), *_split_ws_for(st), st)
     rc = [0]
 
     def run():
@@ -343,7 +343,17 @@ def _splitk_for(n_out_tiles: int, ktiles: int, target_blocks: int) -> int:
     # as many k-slices as keep tiles x slices within ONE round of workgroups over the chip (a second, partly filled
     # round costs more than the slightly lower fill), and >= 8 k-tiles (512 token rows) per slice
     s = max(1, target_blocks // n_out_tiles)
-    return max(1, min(s, ktiles // 8 if ktiles >= 8 else 1))
+    s = max(1, min(s, ktiles // 8 if ktiles >= 8 else 1))
+    if s > 1 and target_blocks == 256:
+        # ... unless the split costs more than it saves (round 6, small batches): every workgroup ends with 256 KiB of fp32 atomics,
+        # which the L2s retire at ~1.2 TB/s in all -- 0.22 us per tile and slice -- against ~1.4 us per k-tile of the main loop
+        # (fitted on graph-replayed launches, tools/gemm_small_fit.py / profiles/r06_gemm_small_fit.txt).  One volume per step
+        # (21 k-tiles): the fc1 + fc2 pair as 128 tiles x 2 slices was 68 us, unsplit (one atomic add per element) it is 54 us.
+        # From 32 volumes per micro-batch on the minimum is the old choice (the most slices that fit one round).
+        def cost(k):
+            return 1.4 * -(-ktiles // k) + 0.22 * n_out_tiles * k
+        s = min(range(1, s + 1), key=cost)
+    return s
 
 
 def linear_wgrad_accum(dy: torch.Tensor, x: torch.Tensor, gw: torch.Tensor, gb: Optional[torch.Tensor] = None):
@@ -451,8 +461,8 @@ ATTN_BWD_FUSED = {32: True, 64: True}
 
 def set_option(key: str, value: int) -> int:
     """octmae_set_option: kernel-selection switch for A/B measurements and tests ("attn_bwd_hd32_form" / "attn_bwd_hd64_form":
-    1 = one wave per SIMD (default), 0 = the two-waves-per-SIMD kernel; "gemm_mfma16": 1 = 16x16x32 MFMAs in the 256-tile
-    forward / dgrad GEMMs, 0 = 32x32x16 (default: no faster in the step); "wgrad_stagger": length step of the k slices of a
+    1 = one wave per SIMD (default), 0 = the two-waves-per-SIMD kernel; "gemm_small": 1 (default) = forward / dgrad launches that
+    would leave most CUs idle take the small-launch kernel, 0 = never; "wgrad_stagger": length step of the k slices of a
     many-way split-K weight gradient, 0 = equal slices).  Returns the previous value."""
     prev = load().octmae_set_option(key.encode(), int(value))
     if prev < 0:

@@ -357,38 +357,49 @@ def test_autocast_invariant_decorator_switches_the_context_off_for_forward_metho
     assert getattr(Inv.forward, "_octmae_no_autocast", False) and not hasattr(Inv.helper, "_octmae_no_autocast")
 
 
-def test_streamk_plan_never_leaves_a_workgroup_without_work():
-    """The stream-K kernel's hand-off has ONE way to hang: a workgroup whose span of k-tiles is empty publishes nothing, and the owner
-    of the tile it was planned into waits for its flag for ever.  The planner (csrc/gemm.hip sk_plan, reached without a GPU through
-    octmae_gemm_streamk_plan) must therefore give every stream-K workgroup >= 1 k-tile -- in fact >= 4 -- for every launch shape, under
-    both planning options; and it must leave alone what it was measured not to help (full rounds, nearly empty or nearly full last
-    rounds, short k-loops below one round of tiles)."""
+def test_small_launch_plan():
+    """The cost model that sends a forward / dgrad GEMM to the small-launch kernel (csrc/gemm.hip plan128, reached without a GPU through
+    octmae_gemm_small_plan).  Properties the kernel relies on: 1 <= slices <= 4, no EMPTY slice (its workgroup would publish a zero
+    tile -- harmless -- but a tile whose counter never reaches `slices` would never be written: (S - 1) * ceil(ktiles / S) < ktiles),
+    a split only with the workspace lent and within its 1024 slots, a ring of 4 or 2 stages.  Policy: the Linear shapes of ONE
+    volume (the reference's shipped recipe) take it and the long reductions are split; the shapes of the headline step (32 / 64 / 128
+    volumes per micro-batch) never do."""
     from octcubem_amd import _lib
     lib = _lib.load()
-    g = ctypes.c_int(0)
-    for opt in (1, 2):
-        prev = lib.octmae_set_option(b"gemm_streamk", opt)
-        try:
-            for cus in (256, 304, 64):
-                for ktiles in (1, 3, 4, 8, 16, 24, 32, 48, 64, 100):
-                    for nt in list(range(1, 3 * cus + 7)) + [10 * cus + 4, 40 * cus + cus // 2]:
-                        skt = lib.octmae_gemm_streamk_plan(nt, ktiles, cus, ctypes.byref(g))
-                        assert 0 <= skt <= nt
-                        if skt == 0:
+    S, st = ctypes.c_int(0), ctypes.c_int(0)
+
+    def plan(NA, NB, K, cus=256, ws=1, big=1):
+        use = lib.octmae_gemm_small_plan(NA, NB, K, cus, ws, big, ctypes.byref(S), ctypes.byref(st))
+        assert use in (0, 1)
+        return use, S.value, st.value
+
+    for cus in (256, 304, 64):
+        for NA in (512, 1024, 1536, 2048, 3072, 4096):
+            for NB in (1, 64, 1281, 2562, 5121, 4 * 1281, 8 * 5121, 32 * 1281, 128 * 5121):
+                for K in (64, 512, 768, 1024, 2048, 3072, 4096):
+                    for ws in (0, 1):
+                        use, s_, n_ = plan(NA, NB, K, cus, ws, int(NA >= 256 and NB >= 256))
+                        kt = K // 64
+                        assert 1 <= s_ <= 4 and n_ in (2, 4)
+                        if not use:
+                            assert s_ == 1
                             continue
-                        G, W = g.value, skt * ktiles
-                        assert 1 <= G <= cus and W >= 4 * G, (opt, cus, ktiles, nt, skt, G)
-                        spans = [(W * i // G, W * (i + 1) // G) for i in range(G)]
-                        assert all(e - s_ >= 4 for s_, e in spans), (opt, cus, ktiles, nt, skt, G)
-                        assert spans[0][0] == 0 and spans[-1][1] == W and all(spans[i][1] == spans[i + 1][0] for i in range(G - 1))
-                        if nt >= cus:
-                            assert skt == nt % cus and ktiles >= 4
-                            if opt == 1:
-                                assert cus <= 8 * skt and 10 * skt <= 8 * cus      # the window: 1/8 ... 80 % of a round
-                        else:
-                            assert skt == nt and G == 4 * nt and ktiles >= 48       # four equal parts of >= 12 k-tiles
-        finally:
-            lib.octmae_set_option(b"gemm_streamk", prev)
-    assert lib.octmae_set_option(b"gemm_streamk", 0) >= 0
-    assert lib.octmae_gemm_streamk_plan(300, 16, 256, ctypes.byref(g)) == 0          # switched off: never
-    lib.octmae_set_option(b"gemm_streamk", 1)
+                        assert ws or s_ == 1
+                        if s_ > 1:
+                            assert (s_ - 1) * -(-kt // s_) < kt and kt // s_ >= 8
+                            assert -(-NA // 128) * -(-NB // 128) * s_ <= 1024
+    # one volume per step: every forward / dgrad Linear of the encoder (1281 rows, D 1024) and decoder (5121 rows, D 512)
+    for NA, NB, K in ((3072, 1281, 1024), (1024, 1281, 1024), (4096, 1281, 1024), (1024, 1281, 4096), (1024, 1281, 3072),
+                      (1536, 5121, 512), (512, 5121, 512), (512, 5121, 2048)):
+        assert plan(NA, NB, K)[0] == 1, (NA, NB, K)
+    assert plan(1024, 1281, 4096)[1] > 1 and plan(1024, 1281, 4096, ws=0)[1] == 1       # the long reductions are split when they can be
+    # the headline step never takes it
+    for vols in (32, 64, 128):
+        for NA, rows, K in ((3072, 1281, 1024), (1024, 1281, 1024), (4096, 1281, 1024), (1024, 1281, 4096), (1024, 1281, 3072),
+                            (1536, 5121, 512), (512, 5121, 512), (2048, 5121, 512), (512, 5121, 2048), (512, 5121, 1536)):
+            assert plan(NA, vols * rows, K)[0] == 0, (vols, NA, rows, K)
+    prev = lib.octmae_set_option(b"gemm_small", 0)
+    try:
+        assert plan(1024, 1281, 4096)[0] == 0                                              # switched off: never
+    finally:
+        lib.octmae_set_option(b"gemm_small", prev)

@@ -77,20 +77,24 @@ GEMM_SHAPES = [(128, 128, 64), (256, 384, 128), (200, 136, 72), (1281, 384, 128)
                (600, 4096, 256), (700, 512, 4096)]      # 16 column tiles, K <= 1024: the column-grouped tile order (forward / dgrad)
 
 
-@pytest.fixture(params=["auto", "tile128", "twostage", "phased", "mfma16"])
+@pytest.fixture(params=["auto", "tile128", "twostage", "phased", "small4", "small2", "small4_split3", "small2_split2", "never_small"])
 def tile_variant(request):
-    """Every GEMM problem runs through the automatic choice (256-tile LDS-DMA kernel with the phased main loop when it fits),
-    through the 128-tile register-staged kernel, through both main loops of the 256-tile kernel (two-stage, phased) and
-    through the phased loop on 16x16x32 MFMAs ("mfma16": gemm256q_kernel for the forward / dgrad kinds)."""
+    """Every GEMM problem runs through the automatic choice (the cost model of csrc/gemm.hip: the small-launch kernel or the 256-tile
+    LDS-DMA kernel with the phased main loop when it fits), through the 128-tile register-staged kernel, through both main loops
+    of the 256-tile kernel (two-stage, phased), through the small-launch kernel (gemm128d_kernel: forward / dgrad kinds with
+    N % 8 == 0 and whole k-tiles) with its 4- and 2-stage rings, unsplit and with a 3- / 2-way deterministic k split, and through
+    the pre-round-6 choice (never the small-launch kernel)."""
     ops.FORCE_SMALL_TILE = request.param == "tile128"
     ops.FORCE_TWO_STAGE = request.param == "twostage"
     ops.FORCE_PHASED = request.param == "phased"
-    prev = ops.set_option("gemm_mfma16", 1 if request.param == "mfma16" else 0)
+    ops.FORCE_SMALL_LAUNCH = {"small4": 4, "small2": 2, "small4_split3": 4, "small2_split2": 2, "never_small": -1}.get(request.param, 0)
+    ops.FORCE_SPLITK = {"small4_split3": 3, "small2_split2": 2}.get(request.param, 1)
     yield request.param
     ops.FORCE_SMALL_TILE = False
     ops.FORCE_TWO_STAGE = False
     ops.FORCE_PHASED = False
-    ops.set_option("gemm_mfma16", prev)
+    ops.FORCE_SMALL_LAUNCH = 0
+    ops.FORCE_SPLITK = 1
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)

@@ -292,9 +292,22 @@ def test_full_size_properties_batch2():
     assert float(mask.sum()) == 2 * 3840 and torch.equal(mask, (ir >= 1280).float())
     assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
     assert float(m.high_res_patch_embed.proj.weight.grad.abs().max()) == 0.0
+    # Row b of a batch == the same volume alone.  Exactly (1e-6) when no GEMM is k-split: every kernel then adds a row's products in
+    # the same order whatever the number of rows.  The small-launch kernel's deterministic k split (round 6) is chosen from the TILE
+    # COUNT, i.e. from the number of token rows: one volume alone splits the K = 3072 / 4096 reductions two ways, two volumes three ways
+    # -- another order of the same fp32 additions, a 1-ulp flip of a 16-bit rounding here and there, and from there the chain's own
+    # sensitivity (a 1e-7 perturbation of the parameters moves pred by 3.6-3.9e-3).  As with the reference's
+    # cuBLAS heuristics, bit-equality across batch sizes is not a property of the fast path; it is one of the unsplit path.
     with torch.no_grad():
         l1, p1, _ = m(imgs[1:], mask_ratio=0.75, noise=noise[1:])
-    assert rel(p1, pred[1:].detach()) <= 1e-6
+        prev, ops.SPLIT_WS = ops.SPLIT_WS, False
+        try:
+            _, p2u, _ = m(imgs, mask_ratio=0.75, noise=noise)
+            _, p1u, _ = m(imgs[1:], mask_ratio=0.75, noise=noise[1:])
+        finally:
+            ops.SPLIT_WS = prev
+    assert rel(p1u, p2u[1:]) <= 1e-6
+    assert rel(p1, pred[1:].detach()) <= 1e-2 and rel(p1, p1u) <= 1e-2          # measured 3.7e-3
 
 
 def test_fused_block_backward_with_shared_activation():
