@@ -199,6 +199,144 @@ def pmc_traffic(kind, micro_batch):
     return None, None, None, None
 
 
+def bring_up_native_comm(store, rank, world, local_rank, comm_cls, fail_rank=None, poll=0.5, timeout=300.0):
+    """The native communicator of this rank -- or the END of the process, with status 3, on EVERY rank when ANY rank cannot create
+    it: ncclCommInitRank is collective, so the peers of a rank whose creation failed would otherwise sit in it for ever.  The
+    failing rank publishes a key in the control-plane store (torch.distributed's, which also carries the RCCL unique id:
+    comm.NativeComm.from_store); a watchdog thread on every rank polls that key while the rank itself may be blocked inside the
+    creation, and ends the process (os._exit: nothing in this process can be unwound out of a blocked RCCL call).  Ranks that
+    succeeded count themselves in and wait for all `world` of them before the watchdog stands down (a peer may still fail after this
+    rank succeeded).  `comm_cls`: comm.NativeComm; the CPU tests pass a gloo-backed stand-in with the same from_store protocol
+    (tests/test_cpu_parallel.py).  `fail_rank`: tests -- that rank's creation fails."""
+    import threading
+    fail_key, ok_key, done = "octmae/bench/comm_failed", "octmae/bench/comm_ok", threading.Event()
+
+    def _watch():
+        while not done.wait(poll):
+            try:
+                failed = store.check([fail_key])
+            except Exception:
+                return
+            if failed:
+                print(f"[bench] rank {rank}: a peer could not create the native RCCL communicator: exiting with status 3",
+                      file=sys.stderr, flush=True)
+                os._exit(3)
+    threading.Thread(target=_watch, daemon=True).start()
+    try:
+        if fail_rank is not None and str(fail_rank) == str(rank):
+            raise RuntimeError("simulated communicator failure (OCTMAE_BENCH_FAIL_COMM_RANK)")
+        comm = comm_cls.from_store(store, rank, world, local_rank)
+    except Exception as e:
+        print(f"[bench] rank {rank}: FATAL: the native RCCL communicator (octmae_comm_*) could not be created: {e!r}.  "
+              "Pass --torch-nccl to measure torch.distributed's NCCL group instead.", file=sys.stderr, flush=True)
+        try:
+            store.set(fail_key, str(rank))
+        except Exception:
+            pass
+        sys.exit(3)
+    store.add(ok_key, 1)
+    t_end = time.time() + timeout
+    while int(store.add(ok_key, 0)) < world and not store.check([fail_key]) and time.time() < t_end:
+        time.sleep(0.05)
+    if store.check([fail_key]) or int(store.add(ok_key, 0)) < world:
+        print(f"[bench] rank {rank}: not every rank created its communicator: exiting with status 3", file=sys.stderr, flush=True)
+        os._exit(3)
+    done.set()
+    return comm
+
+
+def agree_any(comm, flag: bool) -> bool:
+    """True on every rank iff `flag` is true on ANY rank (one MAX all-reduce through the communicator the gradients use)."""
+    return comm.all_reduce_scalar(1.0 if flag else 0.0, MAX_OP) > 0.0
+
+
+def max_over_ranks(comm, value: float) -> float:
+    return comm.all_reduce_scalar(float(value), MAX_OP)
+
+
+MAX_OP = 2      # comm.MAX (octcubem_amd/comm.py; restated so that this file's helpers import nothing before the GPU is chosen)
+
+
+def run_parity_compliant_child(args, steps=5, warmup=1):
+    """The SAME workload on the library that meets the north star's 1e-3 on pred / logits / features (liboctmae_f16.so: the same kernels
+    on IEEE-half operands, the reference's own default arithmetic), in a fresh process with the GPU to itself,
+    through the reference's loss-scaler call -- NativeScalerWithGradNormCount() with GradScaler's dynamic loss scale
+    (main_pretrain_oph_joint_2d512_flash_attn.py:456, custom_util/misc.py:311-344).  Returns the record embedded as
+    `parity_compliant`; the headline value stays the bfloat16 library's (BASELINE's dtype).  A failure is recorded, never raised."""
+    import subprocess
+    lib = os.path.join(ROOT, "octcubem_amd", "liboctmae_f16.so")
+    rec = {"dtype": "f16", "lib": os.path.basename(lib), "value": None, "unit": "volumes/s", "steps": steps, "warmup": warmup,
+           "what": "this bench's workload (global batch 256, same micro-batches, fwd+bwd+AdamW) on the half-operand build of the same "
+                   "kernels, dynamic loss scale as the reference constructs it; a child process run before the parent touched the GPU"}
+    if not os.path.exists(lib):
+        rec["error"] = "liboctmae_f16.so is missing (make -C octcubem_amd/csrc both)"
+        return rec
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-kernel-timing",
+           "--no-per-rank-proxy", "--no-parity-compliant", "--no-small-batch", "--dynamic-loss-scale", "--global-batch", str(args.global_batch),
+           "--micro-batch", str(args.micro_batch)]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, OCTMAE_LIB=lib), capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            rec["error"] = f"rc {r.returncode}: {(r.stderr or r.stdout)[-600:]}"
+            return rec
+        d = json.loads(lines[-1])
+        assert d["dtype"] == "f16", d["dtype"]
+        rec.update({"value": d["value"], "ms_per_step": d["ms_per_step"], "loss": d["loss"], "loss_scale": d["loss_scale"]["scale"],
+                    "dynamic_loss_scale": d["loss_scale"]["dynamic"], "skipped_steps": d["loss_scale"]["skipped_steps"],
+                    "micro_batch_per_gpu": d["config"]["micro_batch_per_gpu"], "peak_allocated_gib": d["memory"]["peak_allocated_gib"]})
+    except Exception as e:      # the headline run must survive whatever happens here
+        rec["error"] = repr(e)[:600]
+    return rec
+
+
+def small_batch_record(model, opt, scaler, params, dev):
+    """The reference's SHIPPED operating point and its neighbours: 1 volume per GPU and step
+    (scripts/run_chunks_pretraining_vitl_oph_joint_flash_attn.sh:25-30), 4 and 8 volumes, and the joint recipe's step -- 1 volume of
+    60x256x256 + 64 B-scans of 512^2 through the high-resolution branch, mask 0.9 / 0.9, ONE optimizer step over the summed loss
+    (Pre-training/engine_pretrain.py:110-127).  Same model, optimizer and kernels as the headline step; device-resident inputs."""
+    import time as _t
+    rec = {"what": "one optimizer step (fwd+bwd+AdamW) over B volumes, B = 1 / 4 / 8, and the shipped joint step (1 volume + 64 B-scans of "
+                   "512x512 as 3-frame volumes, mask 0.9 both); ms per step = wall clock over `steps` steps after `warmup`",
+           "steps": 10, "warmup": 3, "by_volumes": {}}
+    g = torch.Generator(device=dev).manual_seed(4321)
+
+    def timed(fn):
+        for _ in range(rec["warmup"]):
+            fn()
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        for _ in range(rec["steps"]):
+            fn()
+        torch.cuda.synchronize()
+        return (_t.perf_counter() - t0) / rec["steps"]
+
+    for B in (1, 4, 8):
+        x = torch.rand(B, 1, 60, 256, 256, device=dev, generator=g)
+
+        def step():
+            opt.zero_grad()
+            loss, _, _ = model(x, mask_ratio=0.75)
+            scaler(loss, opt, parameters=params)
+        dt = timed(step)
+        rec["by_volumes"][str(B)] = {"ms_per_step": 1e3 * dt, "volumes_per_s": B / dt}
+        del x
+    try:
+        vol = torch.rand(1, 1, 60, 256, 256, device=dev, generator=g)
+        scans = torch.rand(64, 1, 3, 512, 512, device=dev, generator=g)
+
+        def joint():
+            opt.zero_grad()
+            (l3, _frame_loss), _, _ = model(vol, mask_ratio=0.9, frame_loss=True)
+            l2, _, _ = model(scans, mask_ratio=0.9)
+            scaler(l3 + l2, opt, parameters=params)
+        dt = timed(joint)
+        rec["joint_recipe_step"] = {"ms_per_step": 1e3 * dt, "volumes": 1, "bscans_512": 64}
+    except Exception as e:
+        rec["joint_recipe_step"] = {"ms_per_step": None, "error": repr(e)[:300]}
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,7 +357,7 @@ def main():
                          "a one-GPU box (RCCL refuses two ranks on one device); the number it prints is not a benchmark")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=INT",
                     help="kernel-selection switches for same-box A/B runs of the WHOLE step: octmae_set_option keys (attn_bwd_hd32_form, "
-                         "attn_bwd_hd64_form, attn_bwd_tail_fused, gemm_mfma16) or ops.<NAME> flags (ops.FORCE_TWO_STAGE=1, "
+                         "attn_bwd_hd64_form, attn_bwd_tail_fused, gemm_small, wgrad_s1_atomic) or ops.<NAME> flags (ops.FORCE_TWO_STAGE=1, "
                          "ops.ATTN_BWD_FUSED32=0, ...); repeatable.  Isolated kernel A/Bs do not always carry over to the step "
                          "(DESIGN.md section 5, round 4), so defaults are decided here")
     ap.add_argument("--host-inputs", type=int, default=0, choices=[0, 1, 2],
@@ -227,6 +365,12 @@ def main():
                          "host memory and is copied on the compute stream, as the engines do (samples.to(device, non_blocking=True)); "
                          "2: the same copies on a side stream, one micro-batch ahead.  For the PCIe-inclusive rate noted in DESIGN.md; "
                          "never the headline value")
+    ap.add_argument("--no-parity-compliant", action="store_true",
+                    help="N = 1: skip the child run of the same workload on the half-operand build (the `parity_compliant` record)")
+    ap.add_argument("--no-small-batch", action="store_true", help="N = 1: skip the `small_batch` record (1 / 4 / 8 volumes per step + the joint recipe step)")
+    ap.add_argument("--dynamic-loss-scale", action="store_true",
+                    help="the loss scaler as the reference constructs it, NativeScalerWithGradNormCount(): GradScaler's dynamic loss scale "
+                         "when the library computes on half operands (OCTMAE_LIB=liboctmae_f16.so), the identity on bfloat16")
     ap.add_argument("--same-data", action="store_true",
                     help="diagnostic: every rank draws the SAME volumes (seed without the rank) -- with identical weights and masking "
                          "noise the ranks' losses must then be bit-equal (comm.last_loss_min_max_over_ranks)")
@@ -240,6 +384,10 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    parity_compliant = None
+    if world == 1 and args.gpus == 1 and not args.no_parity_compliant and not args.force_reducer and args.global_batch == 256 \
+            and os.environ.get("OCTMAE_LIB") is None:
+        parity_compliant = run_parity_compliant_child(args)          # BEFORE this process touches the GPU; the child has it to itself
     local_rank = 0 if args.gloo_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("OCTMAE_BENCH_FORCE_LOCAL_RANK") is not None:      # tests: several ranks on one GPU with the NATIVE backend selected
         local_rank = int(os.environ["OCTMAE_BENCH_FORCE_LOCAL_RANK"])
@@ -280,46 +428,9 @@ def main():
         elif args.torch_nccl:
             comm_kind = "torch.distributed nccl (--torch-nccl)"
         else:
-            # EVERY rank leaves with status 3 when ANY rank cannot create the communicator: ncclCommInitRank is collective, so the
-            # peers of a rank whose creation failed would otherwise sit in it for ever.  The failing rank publishes a key in the
-            # control-plane store; a watchdog thread on every rank polls that key while the rank itself may be blocked inside the
-            # creation, and ends the process (os._exit: nothing in this process can be unwound out of a blocked RCCL call).
-            import threading
             store = dist.distributed_c10d._get_default_store()
-            fail_key, done = "octmae/bench/comm_failed", threading.Event()
-
-            def _watch():
-                while not done.wait(0.5):
-                    try:
-                        failed = store.check([fail_key])
-                    except Exception:
-                        return
-                    if failed:
-                        print(f"[bench] rank {rank}: a peer could not create the native RCCL communicator: exiting with status 3",
-                              file=sys.stderr, flush=True)
-                        os._exit(3)
-            threading.Thread(target=_watch, daemon=True).start()
-            try:
-                if os.environ.get("OCTMAE_BENCH_FAIL_COMM_RANK") == str(rank):      # tests: this rank's creation fails
-                    raise RuntimeError("simulated communicator failure (OCTMAE_BENCH_FAIL_COMM_RANK)")
-                comm = ocomm.NativeComm.from_store(store, rank, world, local_rank)
-            except Exception as e:
-                print(f"[bench] rank {rank}: FATAL: the native RCCL communicator (octmae_comm_*) could not be created: {e!r}.  "
-                      "Pass --torch-nccl to measure torch.distributed's NCCL group instead.", file=sys.stderr, flush=True)
-                try:
-                    store.set(fail_key, str(rank))
-                except Exception:
-                    pass
-                sys.exit(3)
-            # every rank is through: count them in before the watchdog stands down (a peer may still fail after this rank succeeded)
-            store.add("octmae/bench/comm_ok", 1)
-            t_end = time.time() + 300
-            while int(store.add("octmae/bench/comm_ok", 0)) < world and not store.check([fail_key]) and time.time() < t_end:
-                time.sleep(0.05)
-            if store.check([fail_key]) or int(store.add("octmae/bench/comm_ok", 0)) < world:
-                print(f"[bench] rank {rank}: not every rank created its communicator: exiting with status 3", file=sys.stderr, flush=True)
-                os._exit(3)
-            done.set()
+            comm = bring_up_native_comm(store, rank, world, local_rank, ocomm.NativeComm,
+                                        fail_rank=os.environ.get("OCTMAE_BENCH_FAIL_COMM_RANK"))
             ocomm.set_default(comm)
             comm_kind = "octmae_comm (RCCL behind the C ABI)"
 
@@ -345,7 +456,10 @@ def main():
     if reducer is not None:
         reducer.broadcast_parameters(0)
     opt = foptim.FusedAdamW(misc.add_weight_decay(model, 0.05), lr=1.6e-3 * args.global_batch / 256, betas=(0.9, 0.95))
-    scaler = misc.NativeScalerWithGradNormCount(fp32=True, reducer=reducer)
+    # bfloat16 needs no loss scale (fp32=True: the identity whatever the library); --dynamic-loss-scale: the reference's own call,
+    # GradScaler's state machine on the half build (main_pretrain_oph_joint_2d512_flash_attn.py:456, custom_util/misc.py:311-344)
+    scaler = misc.NativeScalerWithGradNormCount(fp32=not args.dynamic_loss_scale, reducer=reducer)
+    skipped_steps = [0]
     params = list(model.parameters())
 
     def fence():
@@ -357,7 +471,7 @@ def main():
 
     def agree_failed(failed: bool) -> bool:
         if comm is not None:
-            return comm.all_reduce_scalar(1.0 if failed else 0.0, ocomm.MAX) > 0.0
+            return agree_any(comm, failed)
         if use_dist:
             t = torch.tensor([1.0 if failed else 0.0], device="cpu" if args.gloo_one_gpu else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -402,6 +516,8 @@ def main():
                 loss_, _, _ = model(fetch(i), mask_ratio=0.75)
                 last = loss_
                 scaler(loss_ / accum_, opt, parameters=params, update_grad=(exchange and i == accum_ - 1), clip_grad=args.clip_grad)
+            if exchange and scaler.enabled and scaler.last_step_skipped:
+                skipped_steps[0] += 1
             return last
         return step_, accum_
 
@@ -450,7 +566,7 @@ def main():
         # the slowest rank's wait is the step's exposed communication: MAX over ranks through the same backend
         if comm_timing is not None:
             if comm is not None:
-                comm_timing["exposed_ms_per_step_max_over_ranks"] = comm.all_reduce_scalar(comm_timing["exposed_ms_per_step"], ocomm.MAX)
+                comm_timing["exposed_ms_per_step_max_over_ranks"] = max_over_ranks(comm, comm_timing["exposed_ms_per_step"])
             elif use_dist:
                 t = torch.tensor([comm_timing["exposed_ms_per_step"]], dtype=torch.float64, device="cpu" if args.gloo_one_gpu else dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -463,7 +579,7 @@ def main():
     kt = ops.KTIMER.summary() if ops.KTIMER is not None else {}
     ops.KTIMER = None
     if comm is not None:
-        dt = comm.all_reduce_scalar(dt, ocomm.MAX)
+        dt = max_over_ranks(comm, dt)
     elif use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.gloo_one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -505,17 +621,25 @@ def main():
                                    "ratio_to_256": (gb / pdt) / main_rate}
             del pstep
 
+    small_batch = None
+    if world == 1 and not args.no_small_batch and args.global_batch == 256 and not use_dist:
+        try:
+            small_batch = small_batch_record(model, opt, scaler, params, dev)
+        except Exception as e:      # the headline number must survive
+            small_batch = {"error": repr(e)[:400]}
+
     if rank == 0:
         vps = args.steps * args.global_batch / dt
         out = {
             "metric": "3D-MAE pretrain volumes/s (ViT-L, 60x256x256, mask 0.75)", "value": vps, "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16" if ops.LP_IS_F16 else "bf16", "data": "synthetic",
             "config": {"workload": "OCTCube ViT-L 3D-MAE pre-train step (fwd+bwd+all-reduce+AdamW), synthetic (1,60,256,256) volumes, "
                                    "mask_ratio 0.75, decoder 512x8x16", "global_batch": args.global_batch,
                        "micro_batch_per_gpu": mb, "accum_steps": accum, "tokens_enc_dec": [1281, 5121],
                        "parallelism": f"dp{world}"},
             "loss": loss_value, "switches": args.set,
+            "loss_scale": {"dynamic": scaler.enabled, "scale": float(scaler.get_scale()), "skipped_steps": skipped_steps[0]},
             "model_tflops_per_s": vps * 3 * FWD_GFLOP_PER_VOLUME / 1e3,
             "mfu_vs_dense_bf16_peak": vps * 3 * FWD_GFLOP_PER_VOLUME / 1e3 / (PEAK_BF16_TFLOPS * world),
         }
@@ -597,6 +721,12 @@ def main():
                            # ranks see different volumes (seed + rank), so their last-step losses differ slightly; identical
                            # weights after the exchange keep them within sampling noise of each other
                            "last_loss_min_max_over_ranks": list(loss_minmax)}
+        if parity_compliant is not None:
+            if parity_compliant.get("value"):
+                parity_compliant["ratio_to_headline"] = parity_compliant["value"] / vps
+            out["parity_compliant"] = parity_compliant
+        if small_batch is not None:
+            out["small_batch"] = small_batch
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()

@@ -285,7 +285,7 @@ int octmae_mt_adamw_fused(const void* tensor_table, const int* chunk_tensor, con
  * octmae_comm_wait()'s stream has passed it.
  * Return codes: as above, plus -3 = librccl not found at run time, and 10000 + ncclResult_t for an RCCL error. */
 #define OCTMAE_COMM_ID_BYTES 128
-enum { OCTMAE_COMM_F32 = 0, OCTMAE_COMM_BF16 = 1, OCTMAE_COMM_F64 = 2 };
+enum { OCTMAE_COMM_F32 = 0, OCTMAE_COMM_BF16 = 1, OCTMAE_COMM_F64 = 2, OCTMAE_COMM_F16 = 3 /* IEEE half: the 16-bit tensors of liboctmae_f16.so */ };
 enum { OCTMAE_COMM_SUM = 0, OCTMAE_COMM_AVG = 1, OCTMAE_COMM_MAX = 2 };
 int octmae_comm_available(void);                       /* 1 when librccl could be loaded, 0 otherwise (never fails) */
 int octmae_comm_unique_id(void* id_bytes_host);

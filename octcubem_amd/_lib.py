@@ -74,6 +74,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_on_load = []       # callbacks run once, right after the library has been loaded and bound (ops: operand-type check)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "octmae.h")
 
 
@@ -99,7 +100,10 @@ def load():
         raise OctmaeError(
             f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C octcubem_amd/csrc).  There is no CPU or eager fallback.")
-    lib = C.CDLL(LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:        # e.g. a copied .so on a box without the HIP runtime it links against
+        raise OctmaeError(f"{LIB_PATH} could not be loaded: {e}") from e
     for name, argtypes in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
@@ -111,6 +115,8 @@ def load():
         raise OctmaeError(f"{LIB_PATH} reports ABI {lib.octmae_abi_version()}, include/octmae.h declares "
                           f"{expected_abi_version()}: rebuild (make -C octcubem_amd/csrc)")
     _lib = lib
+    for cb in list(_on_load):
+        cb(lib)
     return lib
 
 

@@ -25,6 +25,10 @@ ALIGN = 64  # elements; keeps every tensor 256-byte (fp32) / 128-byte (bf16) ali
 # OCTMAE_ALWAYS_REFRESH_LP=1: cast the whole arena before every forward, as until round 4 (the escape hatch for code that edits
 # weights behind PyTorch's back -- through ``.data`` -- which no version counter sees)
 ALWAYS_REFRESH_LP = os.environ.get("OCTMAE_ALWAYS_REFRESH_LP", "0") == "1"
+# The guard behind the skipped cast: every CHECK_LP_EVERY-th skipped refresh compares a sample of the operand copy with
+# the master weights on the device (a few elements of EVERY parameter + every 4099th element of the arena: one gather, one host
+# read) and, on a mismatch, warns and re-casts.  OCTMAE_CHECK_LP=1: on every refresh (the test suites); OCTMAE_CHECK_LP_EVERY=0: never.
+CHECK_LP_EVERY = 1 if os.environ.get("OCTMAE_CHECK_LP", "0") == "1" else int(os.environ.get("OCTMAE_CHECK_LP_EVERY", "64"))
 
 _OWNER: Dict[int, tuple] = {}      # id(param) -> (weakref(param), weakref(arena)): which arena a parameter lives in
 
@@ -100,6 +104,8 @@ class ParamArena:
             for k in [k for k, (r, a) in _OWNER.items() if r() is None or a() is None]:
                 del _OWNER[k]
         self._lp_state = None
+        self._lp_skips = 0
+        self._lp_sample = None
         self.root = lambda: None          # weakref to the module that bound this arena (bind_arena)
         self.refresh_lp()
 
@@ -134,12 +140,38 @@ class ParamArena:
         # logit-scale clamp of the contrastive step) bump ITS version counter -- the arena's own tensor does not see them
         return sum(p._version for _, p, _, _ in self.entries)
 
+    def lp_matches(self) -> bool:
+        """Does the operand copy still equal the cast of the master weights -- on a SAMPLE: first / middle / last element of every
+        parameter and every 4099th element of the arena?  One device gather + one host read (~0.1 ms); not callable while a HIP graph
+        is being captured."""
+        if self._lp_sample is None or self._lp_sample.device != self.flat.device:
+            idx = []
+            for _, _, o, n in self.entries:
+                idx += [o, o + n // 2, o + n - 1]
+            idx = torch.tensor(idx, dtype=torch.int64)
+            idx = torch.cat([idx, torch.arange(0, self.flat.numel(), 4099, dtype=torch.int64)])
+            self._lp_sample = idx.to(self.flat.device)
+        i = self._lp_sample
+        return bool(torch.equal(self.flat[i].to(self.lp.dtype), self.lp[i]))
+
     def refresh_lp(self, force: bool = False):
         """Bring the 16-bit operand copy up to date with the fp32 master weights: one cast pass over the arena (6 B per parameter)
         -- skipped when nothing has written the parameters since the last pass except FusedAdamW, whose kernel writes the copy of
-        what it updates itself (octmae_mt_adamw_fused).  "Nothing" = the sum of the parameters' PyTorch version counters."""
+        what it updates itself (octmae_mt_adamw_fused).  "Nothing" = the sum of the parameters' PyTorch version counters.
+        Writes that no version counter sees (``p.data.copy_()``, ``dist.broadcast(p.data)``, EMA swaps through ``.data``, raw-pointer
+        kernels, anything written to ``arena.flat``) MUST be followed by ``invalidate_lp()`` -- on the model: ``model.invalidate_lp()``
+        -- (INTEGRATION.md section 1); the sampled guard below catches a forgotten call within CHECK_LP_EVERY forwards and says so."""
         vs = self._versions()
         if not (force or ALWAYS_REFRESH_LP) and self._lp_state == vs:
+            self._lp_skips += 1
+            if CHECK_LP_EVERY > 0 and self._lp_skips % CHECK_LP_EVERY == 0 and self.flat.is_cuda \
+                    and not torch.cuda.is_current_stream_capturing() and not self.lp_matches():
+                import warnings
+                warnings.warn("octcubem_amd: the 16-bit operand copy of the parameter arena no longer matches the fp32 master weights: "
+                              "something wrote parameters behind PyTorch's version counters (p.data.copy_(), dist.broadcast(p.data), an "
+                              "EMA swap through .data, a raw-pointer kernel).  Re-casting now; call model.invalidate_lp() after such "
+                              "writes -- up to OCTMAE_CHECK_LP_EVERY forwards have run on stale operands.", RuntimeWarning, stacklevel=3)
+                ops.cast_bf16_into(self.flat, self.lp)
             return
         ops.cast_bf16_into(self.flat, self.lp)
         self._lp_state = vs

@@ -17,9 +17,9 @@ import torch
 
 from ._lib import call, load
 
-F32, BF16, F64 = 0, 1, 2
+F32, BF16, F64, F16 = 0, 1, 2, 3
 SUM, AVG, MAX = 0, 1, 2
-_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float64: F64}
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float64: F64, torch.float16: F16}      # F16: collectives of the half-operand build
 ID_BYTES = 128
 
 _default: Optional["NativeComm"] = None
@@ -57,13 +57,17 @@ class NativeComm:
         ranks have joined), so the ``world`` arrivals of one creation are complete before the first of the next.  A second
         communicator on the same store (re-initialisation after destroy(), a library and a benchmark both bootstrapping) can
         therefore never read the previous, stale id and hang with mismatched ids."""
-        torch.cuda.set_device(device)
+        cls._set_device(device)
         gen = (int(store.add(key + "/arrivals", 1)) - 1) // world
         skey = f"{key}#{gen}"
         if rank == 0:
             store.set(skey, cls.unique_id())
         id_bytes = bytes(store.get(skey))
         return cls(id_bytes, rank, world, device)
+
+    @staticmethod
+    def _set_device(device: int):
+        torch.cuda.set_device(device)
 
     @classmethod
     def from_env(cls, device: Optional[int] = None, tag: str = "0") -> "NativeComm":
@@ -92,7 +96,7 @@ class NativeComm:
     @staticmethod
     def _check(t: torch.Tensor):
         if not (t.is_cuda and t.is_contiguous() and t.dtype in _DT):
-            raise RuntimeError("NativeComm: contiguous fp32 / bf16 / fp64 GPU tensors only")
+            raise RuntimeError("NativeComm: contiguous fp32 / bf16 / fp16 / fp64 GPU tensors only")
 
     def all_reduce_async(self, t: torch.Tensor, op: int = SUM):
         self._check(t)

@@ -117,6 +117,7 @@ bool dtype_of(int dtype, ncclDataType_t* t) {
     case OCTMAE_COMM_F32: *t = ncclFloat32; return true;
     case OCTMAE_COMM_BF16: *t = ncclBfloat16; return true;
     case OCTMAE_COMM_F64: *t = ncclFloat64; return true;
+    case OCTMAE_COMM_F16: *t = ncclFloat16; return true;
     default: return false;
   }
 }

@@ -59,6 +59,7 @@ struct GemmParams {
   int kstagger;            // split-K: 0 = equal k slices; d > 0 = slice z is d / 256 k-tiles longer than slice z - 1 (split_range)
   int ldc2;                // EPI_DGELU column sums: 0 = C2 is an fp32 [NA] vector (atomics); > 0 = C2 is fp32 [NB / 64][ldc2],
                            // one row of partial sums per 64-row slab, plain stores (folded by a second launch)
+  int dgelu_stored = 0;    // EPI_GELU: C receives gelu'(pre) instead of pre; EPI_DGELU: aux holds gelu'(pre) already (variant bit 15)
   int atomic1 = 0;         // EPI_ACCUM, UNSPLIT launch: 0 guarded read-modify-write, 1 fp32 atomics, 2 batched buffer read-modify-write (g_wgrad_s1_atomic)
 };
 
@@ -194,7 +195,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + o) = w;
           } else if (EPI == EPI_GELU) {
             u32x2 w = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-            *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + o) = w;
+            if (p.dgelu_stored) {
+              const u32x2 wd = {pack2bf(dgelu_f(bflo(w[0])), dgelu_f(bfhi(w[0]))), pack2bf(dgelu_f(bflo(w[1])), dgelu_f(bfhi(w[1])))};
+              *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + o) = wd;
+            } else {
+              *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + o) = w;
+            }
             // activation of the bf16-ROUNDED pre-activation, so backward (which only has the
             // rounded value) differentiates exactly the function the forward evaluated
             float y[4];
@@ -209,8 +215,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + o) = w;
           } else if (EPI == EPI_DGELU) {
             const u32x2 pre = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.aux) + (size_t)b * p.ldaux + a);
-            v[0] *= dgelu_f(bflo(pre[0])); v[1] *= dgelu_f(bfhi(pre[0]));
-            v[2] *= dgelu_f(bflo(pre[1])); v[3] *= dgelu_f(bfhi(pre[1]));
+            if (p.dgelu_stored) {
+              v[0] *= bflo(pre[0]); v[1] *= bfhi(pre[0]); v[2] *= bflo(pre[1]); v[3] *= bfhi(pre[1]);
+            } else {
+              v[0] *= dgelu_f(bflo(pre[0])); v[1] *= dgelu_f(bfhi(pre[0]));
+              v[2] *= dgelu_f(bflo(pre[1])); v[3] *= dgelu_f(bfhi(pre[1]));
+            }
             u32x2 w = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
             *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + o) = w;
           }
@@ -465,6 +475,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
         if (pass == 1) {   // activation of the bf16-ROUNDED pre-activation (what backward differentiates)
           const f32x2 y0 = gelu_f2(f32x2{bflo(w[0]), bfhi(w[0])}), y1 = gelu_f2(f32x2{bflo(w[1]), bfhi(w[1])});
           w = u32x2{pack2bf(y0[0], y0[1]), pack2bf(y1[0], y1[1])};
+        } else if (EPI == EPI_GELU && p.dgelu_stored) {   // ... or its derivative there, for the fc2 dgrad's epilogue to multiply with
+          const f32x2 y0 = dgelu_f2(f32x2{bflo(w[0]), bfhi(w[0])}), y1 = dgelu_f2(f32x2{bflo(w[1]), bfhi(w[1])});
+          w = u32x2{pack2bf(y0[0], y0[1]), pack2bf(y1[0], y1[1])};
         }
         *reinterpret_cast<u32x2*>(wl + off(row, chunk) + 8 * half8) = w;
       };
@@ -489,7 +502,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
           const u32x4 pre = prev[it];   // zeros outside the matrix: gelu'(0) * v is stored nowhere and summed nowhere
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const f32x2 y = f32x2{bflo(v[e]), bfhi(v[e])} * dgelu_f2(f32x2{bflo(pre[e]), bfhi(pre[e])});
+            const f32x2 pv = f32x2{bflo(pre[e]), bfhi(pre[e])};
+            const f32x2 y = f32x2{bflo(v[e]), bfhi(v[e])} * (p.dgelu_stored ? pv : dgelu_f2(pv));
             v[e] = pack2bf(y[0], y[1]);
           }
           if (p.C2 != nullptr && b_base + row < p.NB) {
@@ -1083,11 +1097,12 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm128d_kernel(const G
       else if (NST == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      stage(it + NST - 1);
       const char* cA = smem + (it % NST) * D_STAGE;
       const char* cB = cA + TILE_BYTES;
       // all 16 fragment reads of the k-tile first, into registers of their own (a wave is alone on its SIMD: 512 registers),
-      // the 16 MFMAs behind them: the matrix pipe waits for the first k-step's reads only, the rest arrive under it
+      // the 16 MFMAs behind them: the matrix pipe waits for the first k-step's reads only, the rest arrive under it; the ring's
+      // next requests go out BEHIND the reads (their slot, tile it - 1's, is free since the barrier): their issue runs under the
+      // reads' latency instead of in front of it
       bf16x8 fa[4][2], fb[4][2];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -1096,6 +1111,8 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm128d_kernel(const G
 #pragma unroll
         for (int j = 0; j < 2; ++j) fb[s][j] = read_fragH<B_KS>(cB, wb * 64 + j * 32, s, lane);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      stage(it + NST - 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
@@ -1168,7 +1185,7 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm128d_kernel(const G
 // 1/256 k-tiles PER OUTPUT TILE of the launch (the atomic time of a slice grows with its tile count: 256 KiB at 1.35 TB/s = 0.19 us
 // per tile against 1.7 us per k-tile, i.e. v = 29); 0 = equal slices.  octmae_set_option("wgrad_stagger", v) / OCTMAE_WGRAD_STAGGER.
 // Applied only to splits of >= 8 slices with <= 96 k-tiles each (the [C x C] proj gradients at <= 32 volumes per rank): measured
-// (tools/archive/wgrad_stagger_ab.py, profiles/r04_wgrad_stagger.txt) -9 / -11 % there, and nothing or a loss for the 4- and 5-way splits
+// (profiles/r04_wgrad_stagger.txt) -9 / -11 % there, and nothing or a loss for the 4- and 5-way splits
 // and for every shape at 128 volumes -- their workgroups do not end together anyway.
 std::atomic<int> g_wgrad_stagger{29};
 // The epilogue of an UNSPLIT weight-gradient launch of the phased 256-tile kernel: 0 = plain read-modify-write (one guarded load + store
@@ -1342,6 +1359,7 @@ static int gemm_impl(const void* A, const void* B, void* C, void* C2, const floa
   const int variant = (epilogue >> 8) & 1;
   const int force128 = ((epilogue >> 12) & 1) ? 4 : ((epilogue >> 13) & 1) ? 2 : 0;
   const bool never128 = ((epilogue >> 14) & 1) != 0;
+  const int dgelu_stored = (epilogue >> 15) & 1;        // bit 15: the fc1 forward stores gelu'(pre) / the fc2 dgrad multiplies with it
   // phased main loop by default (dgrad, wgrad: +10..25 % over the two-stage loop; forward, re-measured in round 2 after the
   // epilogue work: qkv -4 %, proj -11 %, fc2 -8 %, fc1 + GELU -1.5 %, decoder fc1 + GELU +0.6 % -- in round 1 the two-stage loop
   // had still been 12 % faster at K = 1024).
@@ -1425,6 +1443,7 @@ static int gemm_impl(const void* A, const void* B, void* C, void* C2, const floa
   p.ldc2 = 0; p.hd = 0;
   p.kstagger = (big && epilogue == EPI_ACCUM) ? wgrad_stagger_for(p.ktiles, splitk, p.tiles_a * p.tiles_b) : 0;
   p.atomic1 = (big && phased && epilogue == EPI_ACCUM) ? wgrad_s1_atomic() : 0;
+  p.dgelu_stored = (epilogue == EPI_GELU || epilogue == EPI_DGELU) ? dgelu_stored : 0;
   // 64-row slabs that write a row of partial column sums: those of the grid that runs (octmae_dgelu_colsum_ws_rows covers both)
   const int ws_rows = pl.use ? 2 * ((NB + T1 - 1) / T1) : 4 * p.tiles_b;
   if (epilogue == EPI_DGELU && p.C2 != nullptr && colsum_ws != nullptr) { p.C2 = colsum_ws; p.ldc2 = NA; }
@@ -1620,6 +1639,6 @@ extern "C" int octmae_linear_dgrad_dgelu(const void* W, const void* dY, void* dX
                                          int M, int N, int K, int ldw, int ldy, int ldx, int ldpre, int variant, void* split_ws,
                                          long long split_ws_bytes, void* stream) {
   OCTMAE_CHECK_ARG(bias_grad == nullptr || ws != nullptr);
-  return gemm_impl(W, dY, dX, bias_grad, nullptr, pre, K, M, N, ldw, ldy, ldx, ldpre, 1, 0, EPI_DGELU | (variant & 0x77F00), 1, stream, nullptr, 1,
+  return gemm_impl(W, dY, dX, bias_grad, nullptr, pre, K, M, N, ldw, ldy, ldx, ldpre, 1, 0, EPI_DGELU | (variant & 0x7FF00), 1, stream, nullptr, 1,
                    bias_grad != nullptr ? ws : nullptr, split_ws, split_ws_bytes);
 }

@@ -160,6 +160,13 @@ class MaskedAutoencoderViT(nn.Module):
     def arena(self):
         return self._arena_views()[0]
 
+    def invalidate_lp(self):
+        """Call after writing weights behind PyTorch's version counters (``p.data.copy_()``, ``dist.broadcast(p.data)``, an EMA swap
+        through ``.data``, a raw-pointer kernel): the next forward re-casts the whole 16-bit operand copy of the parameter arena
+        (INTEGRATION.md section 1).  In-place writes that bump a version counter -- torch.optim optimizers, ``load_state_dict``,
+        ``p.copy_()`` under ``no_grad`` -- are seen without it."""
+        self.arena.invalidate_lp()
+
     def _linear(self, name, x, out_f32=False):
         _, v = self._arena_views()
         w_lp, b32, gw, gb = v[name]

@@ -74,6 +74,13 @@ class VisionTransformer(nn.Module):
     def arena(self):
         return get_arena(self, full_check=True)
 
+    def invalidate_lp(self):
+        """Call after writing weights behind PyTorch's version counters (``p.data.copy_()``, ``dist.broadcast(p.data)``, an EMA swap
+        through ``.data``, a raw-pointer kernel): the next forward re-casts the whole 16-bit operand copy of the parameter arena
+        (INTEGRATION.md section 1).  In-place writes that bump a version counter -- torch.optim optimizers, ``load_state_dict``,
+        ``p.copy_()`` under ``no_grad`` -- are seen without it."""
+        self.arena.invalidate_lp()
+
     def forward_features(self, x):
         self.prepare()
         x = x.float().contiguous()

@@ -21,7 +21,8 @@ from ._lib import OctmaeError, call, load
 
 def _lp_dtype():
     """The torch dtype of the library's 16-bit operand type (octmae_lp_dtype): bfloat16 for liboctmae.so, float16 for the
-    verification build liboctmae_f16.so (OCTMAE_LIB).  A missing library is reported by the first compute call, not here."""
+    verification build liboctmae_f16.so (OCTMAE_LIB).  A library that is missing or cannot be loaded here (a CPU-only box) is
+    reported by the first compute call, not by the import; bfloat16 is assumed until then and CHECKED when the library does load."""
     try:
         return torch.float16 if load().octmae_lp_dtype() == 1 else torch.bfloat16
     except OctmaeError:
@@ -30,6 +31,17 @@ def _lp_dtype():
 
 BF16 = _lp_dtype()                 # named for the shipped build; every "bf16" below means "the library's 16-bit operand type"
 LP_IS_F16 = BF16 == torch.float16
+
+
+def _check_lp_dtype(lib):
+    got = torch.float16 if lib.octmae_lp_dtype() == 1 else torch.bfloat16
+    if got != BF16:
+        raise OctmaeError(f"the library computes on {got} operands but octcubem_amd.ops was imported assuming {BF16} (the library was "
+                          "built or selected after the import): restart the process with OCTMAE_LIB set before importing octcubem_amd")
+
+
+from . import _lib as _libmod  # noqa: E402
+_libmod._on_load.append(_check_lp_dtype)
 F32 = torch.float32
 _CHECK_IDS = os.environ.get("OCTMAE_CHECK_IDS", "0") == "1"    # verify the permutation contract of the assembly ops per call
 
@@ -377,7 +389,7 @@ WGRAD_PAIR = os.environ.get("OCTMAE_WGRAD_PAIR", "1") != "0"
 def linear_wgrad_accum_pair(first, second):
     """Two linear_wgrad_accum calls over the same token rows -- (dy, x, gw, gb) each -- as ONE launch: the tiles of both outputs
     share the split over the rows, so there are half as many fp32-atomic epilogues and the k-loops are twice as long (measured on
-    the combined shape, tools/archive/wgrad_group_bound.py: -12 ... -15 % at 32 volumes, -2 ... -7 % at 128).  Falls back to two launches when
+    the combined shape, profiles/r04_wgrad_pair.txt: -12 ... -15 % at 32 volumes, -2 ... -7 % at 128).  Falls back to two launches when
     the library says the pair does not apply (-2) or WGRAD_PAIR is off."""
     (dy0, x0, gw0, gb0), (dy1, x1, gw1, gb1) = first, second
     M = dy0.shape[0]
@@ -453,7 +465,7 @@ def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, HD: int, scale: float, o
 
 
 # Which backward runs per head_dim: the single-pass kernel (csrc/attn_bwd.hip) or the dQ + dK/dV kernel pair (csrc/attn.hip).
-# Measured on MI355X (tools/archive/attn_bwd_ab.py, same process, interleaved): head_dim 32 (decoder, N = 5121) fused 11 % faster;
+# Measured on MI355X (same process, interleaved; docs/HISTORY.md section 4 "Attention"): head_dim 32 (decoder, N = 5121) fused 11 % faster;
 # head_dim 64 fused 4 % faster at N = 1281 (encoder) and 2 % at N = 5121 (fine-tune) since its LDS-DMA requests go out between
 # the sub-tiles and its sub-tile addressing is hand-placed (before: the pair 10-13 % faster).
 ATTN_BWD_FUSED = {32: True, 64: True}

@@ -202,13 +202,13 @@ def block_backward(saved, dx3: torch.Tensor, fused_bwd: bool = True, poly_dgelu:
     d3b = bf(dx3)
     G["mlp.fc2.weight"] = (d3b.reshape(-1, C).T @ act.reshape(-1, act.shape[-1]))
     G["mlp.fc2.bias"] = dx3.reshape(-1, C).sum(0)
-    # fc2 dgrad x GELU': the 256-tile GEMM kernel rounds the product to bf16 on its way through the epilogue's LDS transpose and
-    # multiplies the ROUNDED value by gelu'(pre) (two roundings); the 128-tile kernel -- taken when a dimension of the GEMM is
-    # below 256 (csrc/gemm.hip `big`: here rows B * N < 256 or hidden < 256 or C % 64 != 0) -- multiplies its fp32 accumulator
-    # and rounds once
+    # fc2 dgrad x GELU': the kernels with the LDS-transposing epilogue -- the 256-tile kernels and, since round 6, the small-launch kernel
+    # that takes every problem the 256-tile kernels do not (csrc/gemm.hip gemm128_ok: hidden % 8 == 0 and whole k-tiles, C % 64 == 0)
+    # -- round the product to bf16 on its way through the LDS transpose and multiply the ROUNDED value by gelu'(pre) (two roundings);
+    # the 128-tile register-staged kernel, what is left for the other shapes, multiplies its fp32 accumulator and rounds once
     dg = dgelu_poly(pre) if (poly_dgelu and not _EXACT) else dgelu(pre)
     hidden = w1.shape[0]
-    big = hidden >= 256 and B * N >= 256 and C % 64 == 0
+    big = hidden % 8 == 0 and C % 64 == 0
     dpre = bf(bf(d3b @ w2) * dg) if big else bf((d3b @ w2) * dg)
     G["mlp.fc1.bias"] = dpre.reshape(-1, dpre.shape[-1]).sum(0)
     G["mlp.fc1.weight"] = dpre.reshape(-1, dpre.shape[-1]).T @ y2.reshape(-1, C)

@@ -9,6 +9,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the sampled guard behind the arena's skipped operand cast checks at EVERY forward in the test suites (octcubem_amd/arena.py;
+# must be set before the package is imported)
+os.environ.setdefault("OCTMAE_CHECK_LP", "1")
+
 
 def pytest_configure(config):
     # The CPU oracle runs inside many GPU tests, beside child processes that run it too (tests/test_gpu_f16_parity.py, the multi-rank
@@ -71,3 +75,18 @@ def _parity_ledger():
     except OSError:
         pass
     print("\n[parity ledger] " + "; ".join(f"{l} {v:.2e} (<= {b:.1e})" for l, v, b in _LEDGER))
+
+
+def pytest_collection_finish(session):
+    """Modules that run helper processes beside the session (tests/test_gpu_f16_parity.py: one ledger per build of the library) start
+    them here -- once the selection is known, and only when at least one of their tests is in it (`-m "not gpu"`, `-k ...` and
+    `--collect-only` start nothing)."""
+    if session.config.option.collectonly:
+        return
+    seen = set()
+    for item in session.items:
+        mod = getattr(item, "module", None)
+        hook = getattr(mod, "start_children", None)
+        if hook is not None and id(mod) not in seen:
+            seen.add(id(mod))
+            hook()

@@ -323,8 +323,154 @@ def case_train(out):
     out["train/loss_scale"] = float(scaler.get_scale())
 
 
+def case_coem_l(out):
+    """BASELINE config 5 at full size (round 6): the shipped tower pair -- ViT-L ST on (2,1,60,256,256), N = 5121, + ViT-L 2-D on
+    (2,3,224,224), embed 512 -- through coem.create_model_from_config, one contrastive step (ClipLoss, backward through both towers)
+    against the pins of the reference's own tower classes and ClipLoss (oracle/gen_golden_coem_full.py;
+    retinal-COEM/src/open_clip/model.py:635-682, loss.py:21-65)."""
+    from octcubem_amd import coem
+    from oracle import vit_ref as V
+    import tests.test_gpu_coem as TC
+    z = np.load(os.path.join(GOLDEN, "coem_l_pins.npz"))
+    model = coem.create_model_from_config(json.loads(json.dumps(TC.SHIPPED_CFG)), flash_semantics=False)
+    PA = V.init_from_shapes(V.vit_st_param_shapes(V.ViTSTConfig(**json.loads(str(z["cfg_a"])))), seed=int(z["seed_a"]))
+    PB = V.init_from_shapes(V.vit2d_param_shapes(V.ViT2DConfig(**json.loads(str(z["cfg_b"])))), seed=int(z["seed_b"]))
+    model.visual.load_state_dict(PA, strict=True); model.text.load_state_dict(PB, strict=True)
+    model = model.to(DEV).eval()
+    vol = torch.rand(2, 1, 60, 256, 256, generator=torch.Generator().manual_seed(int(z["vol_seed"]))).to(DEV)
+    ir = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(int(z["ir_seed"]))).to(DEV)
+    keep = {}
+
+    def fwd():
+        fa, fb, ls = model(vol, ir)
+        keep["fa"], keep["fb"] = fa, fb
+        return coem.ClipLoss()(fa, fb, ls)
+
+    loss, S = backward_scaled(fwd, model)
+    out["coem_l/feat_a"] = rel(keep["fa"], z["feat_a"])
+    out["coem_l/feat_b"] = rel(keep["fb"], z["feat_b"])
+    out["coem_l/loss"] = abs(float(loss) - float(z["loss"])) / abs(float(z["loss"]))
+    out["coem_l/logit_scale_grad"] = abs(float(model.logit_scale.grad) / S - float(z["logit_scale_grad"])) / (abs(float(z["logit_scale_grad"])) + 1e-3)
+    samples = []
+    for tag, tower in (("a", model.visual), ("b", model.text)):
+        names = json.loads(str(z[f"grad_names_{tag}"]))
+        norms = dict(zip(names, z[f"grad_norms_{tag}"]))
+        grads = {k: (p.grad.double() / S if p.grad is not None else torch.zeros_like(p, dtype=torch.float64)) for k, p in tower.named_parameters()}
+        tot = float(torch.sqrt(sum(g.pow(2).sum() for g in grads.values())))
+        ref_tot = float(z[f"tower_grad_norm_{tag}"])
+        out[f"coem_l/tower_grad_norm_{tag}"] = abs(tot - ref_tot) / ref_tot
+        out[f"coem_l/worst_tensor_norm_{tag}"] = max(abs(float(grads[k].norm()) - norms[k]) / norms[k] for k in names if norms[k] >= 1e-2 * ref_tot)
+        for key in z.files:
+            if key.startswith(f"gsample_{tag}/"):
+                k = key.split("/", 1)[1]
+                if norms[k] >= 1e-2 * ref_tot:
+                    samples.append(rel(grads[k].flatten()[::int(z[f"gstep_{tag}/{k}"])][:len(z[key])], z[key]))
+    out["coem_l/grad_samples_max"] = max(samples)
+    out["coem_l/grad_samples_median"] = float(np.median(samples))
+    out["coem_l/loss_scale"] = S
+
+
+def case_finetune(out):
+    """The fine-tune ENGINE (round 6): engine_finetune.train_one_epoch -- lr_decay groups, accumulation, the clip branch of the scaler,
+    FusedAdamW -- over the two epochs of tests/golden/finetune_small.npz, the trajectory the reference's own loop produced
+    (OCTCube/engine_finetune.py:386-482 through oracle/gen_golden_finetune.py).  On the half build the scaler is the reference's
+    GradScaler state machine (no step may be skipped).  Entries: worst per-iteration loss / gradient-norm error, 1 - the smallest
+    cosine between this run's and the reference's total parameter update over the tensors that moved."""
+    import tests.test_gpu_finetune as TF
+    from octcubem_amd import engine_finetune, lr_decay, misc, optim as foptim
+    z = np.load(os.path.join(GOLDEN, "finetune_small.npz"))
+    cfg, P0, model = TF.build(z)
+    xs = torch.rand(6, 2, 1, 12, 64, 64, generator=torch.Generator().manual_seed(int(z["data_seed"])))
+    ts = torch.from_numpy(z["target"])
+    opt = foptim.FusedAdamW(lr_decay.param_groups_lrd(model, 0.05, no_weight_decay_list=model.no_weight_decay(), layer_decay=0.75), lr=TF.Args.lr)
+    scaler = misc.NativeScalerWithGradNormCount()
+    assert scaler.enabled == ops.LP_IS_F16
+    crit = torch.nn.CrossEntropyLoss()
+    rec = {"loss": [], "norm": [], "skipped": 0}
+
+    def rec_crit(o, t):
+        l = crit(o, t); rec["loss"].append(float(l)); return l
+
+    def rec_scaler(loss, optimizer, **kw):
+        n = scaler(loss, optimizer, **kw)
+        rec["norm"].append(-1.0 if n is None else float(n))
+        rec["skipped"] += int(n is not None and scaler.last_step_skipped)
+        return n
+    loader = [(xs[i], ts[i]) for i in range(6)]
+    for epoch in range(2):
+        engine_finetune.train_one_epoch(model, rec_crit, loader, opt, torch.device(DEV), epoch, rec_scaler, 1.0, None, None, TF.Args)
+    assert rec["skipped"] == 0, "the dynamic loss scale skipped a step"
+    losses_, norms = np.array(rec["loss"]), np.array(rec["norm"])
+    assert ((norms < 0) == (z["norms"] < 0)).all()
+    out["finetune/loss_max"] = float(np.max(np.abs(losses_ - z["losses"]) / np.abs(z["losses"])))
+    out["finetune/grad_norm_max"] = float(np.max(np.abs(norms[norms > 0] - z["norms"][z["norms"] > 0]) / z["norms"][z["norms"] > 0]))
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    worst = 0.0
+    for k in z.files:
+        if not k.startswith("final/"):
+            continue
+        n = k[len("final/"):]
+        sub = (lambda t: t if t.numel() <= 8192 else t.flatten()[::7])
+        ref, mine, init = torch.from_numpy(z[k]).flatten(), sub(sd[n]).flatten(), sub(P0[n]).flatten()
+        du_ref, du = (ref - init).double(), (mine - init).double()
+        if n.endswith("attn.k.bias") or float(du_ref.norm()) <= 1e-9:
+            continue
+        worst = max(worst, 1.0 - float((du * du_ref).sum() / (du.norm() * du_ref.norm() + 1e-30)))
+    out["finetune/1-cos(update)_worst"] = worst
+    out["finetune/loss_scale"] = float(scaler.get_scale())
+
+
+def case_joint(out):
+    """The joint pre-training LOOP (round 6): engine_pretrain.train_one_epoch_joint -- 3-D volumes + 2-D/512 B-scan triplets, summed
+    loss, per-frame loss feedback, accumulation, clip, FusedAdamW -- over the epoch of tests/golden/joint_small.npz, produced by the
+    reference's own loop on the same data and masking noise (Pre-training/engine_pretrain.py:29-204 through
+    oracle/gen_golden_joint.py).  Entries: epoch-mean losses, worst gradient-norm and per-frame-loss error."""
+    from functools import partial
+    from octcubem_amd import engine_pretrain, misc, models_mae, optim as foptim
+    from tests.test_oracle_joint_golden import load_joint
+    z, cfg, P0, vols, imgs2d, n3, n2, frames = load_joint(GOLDEN)
+    m = models_mae.MaskedAutoencoderViT(
+        input_size=cfg.input_size, patch_size=cfg.patch_size, in_chans=cfg.in_chans, embed_dim=cfg.embed_dim, depth=cfg.depth,
+        num_heads=cfg.num_heads, decoder_embed_dim=cfg.decoder_embed_dim, decoder_depth=cfg.decoder_depth,
+        decoder_num_heads=cfg.decoder_num_heads, mlp_ratio=cfg.mlp_ratio, norm_layer=partial(torch.nn.LayerNorm, eps=cfg.ln_eps),
+        num_frames=cfg.num_frames, t_patch_size=cfg.t_patch_size, sep_pos_embed=True, cls_embed=True, pred_t_dim=cfg.pred_t_dim,
+        high_res_input_size=cfg.high_res_input_size)
+    m.load_state_dict(P0, strict=True)
+    m = m.to(DEV)
+    opt = foptim.FusedAdamW(misc.add_weight_decay(m, 0.05), lr=1e-3, betas=(0.9, 0.95))
+    scaler = misc.NativeScalerWithGradNormCount()
+    assert scaler.enabled == ops.LP_IS_F16
+    norms, skipped = [], [0]
+
+    def rec_scaler(loss, optimizer, **kw):
+        n = scaler(loss, optimizer, **kw)
+        norms.append(-1.0 if n is None else float(n))
+        skipped[0] += int(n is not None and scaler.last_step_skipped)
+        return n
+    queue = [t for pair in zip(n3, n2) for t in pair]
+    noise_fn = lambda s: queue.pop(0).to(DEV)
+    loader3d = [(vols[it], ([f"vol{it}_{j}" for j in range(2)], {"frames": frames[it]})) for it in range(4)]
+    loader2d = [(imgs2d[it], None) for it in range(4)]
+    table = {f: {} for it in range(4) for nf in range(6) for f in frames[it][nf]}
+
+    class Args:
+        accum_iter = 2; lr = 1e-3; min_lr = 1e-6; warmup_epochs = 1; epochs = 4; mask_ratio = 0.75; clip_grad = 1.0; repeat_aug = 1
+    stats = engine_pretrain.train_one_epoch_joint(m, loader3d, opt, torch.device(DEV), 1, rec_scaler, loader2d, table, 0.8, args=Args,
+                                                  noise_fn=noise_fn)
+    assert skipped[0] == 0, "the dynamic loss scale skipped a step"
+    ref = json.loads(str(z["stats"]))
+    for k in ("loss", "loss_2d", "loss_all"):
+        out[f"joint/{k}"] = abs(stats[k] - ref[k]) / ref[k]
+    nr = np.array(norms); zr = np.asarray(z["norms"], dtype=np.float64)
+    assert ((nr < 0) == (zr < 0)).all()
+    out["joint/grad_norm_max"] = float(np.max(np.abs(nr[nr > 0] - zr[zr > 0]) / zr[zr > 0]))
+    ref_tab = json.loads(str(z["frame_dict"]))
+    out["joint/frame_loss_max"] = max(abs(table[k]["mse_loss"] - e["mse_loss"]) / abs(e["mse_loss"]) for k, e in ref_tab.items())
+    out["joint/loss_scale"] = float(scaler.get_scale())
+
+
 CASES = {"train": case_train, "small": case_small, "mid": case_mid, "mae2d_small": case_mae2d, "vit_st_small": case_vit_st, "vitl": case_vitl,
-         "vit_st_l": case_vit_st_l}
+         "vit_st_l": case_vit_st_l, "coem_l": case_coem_l, "finetune": case_finetune, "joint": case_joint}
 
 
 def main():

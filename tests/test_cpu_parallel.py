@@ -315,11 +315,12 @@ def _worker_world(rank, world, port, q):
     arena.grad.zero_()
     red.begin_backward(sync=True)
     try:
-        arena.params[7].grad.add_(1.0); ops.notify_grad_ready([arena.params[7]])
+        # (only the notification: the cold chunk's asynchronous all-reduce went out at begin_backward() and may still be in flight --
+        # writing its buffer here raced with the collective, one failure in four runs: ADVICE r05)
+        ops.notify_grad_ready([arena.params[7]])
         fail("late gradient for a cold parameter did not raise")
     except RuntimeError:
         pass
-    arena.params[7].grad.zero_()
     for i in range(6, -1, -1):
         arena.params[i].grad.add_(float(rank + 1)); ops.notify_grad_ready([arena.params[i]])
     red.finish()
@@ -401,3 +402,110 @@ def test_control_flow_divergence_raises_instead_of_hanging():
     for r, o in by_rank.items():
         if r != 1:
             assert o["raised"] is None          # the others ran the agreed order; whatever they got came from the broken group
+
+
+# ---- bench.py's control plane at world 8 with a gloo-backed stand-in for the RCCL communicator -------------------
+# RCCL with N > 1 has never run anywhere (no multi-GPU node was available to the builder).  What CAN run without one is everything
+# around the collective calls: comm.NativeComm.from_store's generation-keyed hand-off of the unique id through torch.distributed's
+# store, bench.bring_up_native_comm (watchdog thread, "every rank counted in" gate, exit status 3 on EVERY rank when one fails),
+# bench.agree_any / max_over_ranks (the micro-batch fallback agreement, the step time and exposed-communication MAX).
+
+
+def _fake_comm_class():
+    from octcubem_amd import comm as ocomm
+
+    class GlooComm(ocomm.NativeComm):
+        """comm.NativeComm with the three C-ABI touch points replaced: the unique id is 128 random bytes, "ncclCommInitRank" is a gloo
+        barrier (collective: a rank that never joins blocks its peers, as RCCL's does), collectives run on CPU tensors."""
+        created = []
+
+        def __init__(self, id_bytes, rank, world, device):
+            assert len(id_bytes) == ocomm.ID_BYTES
+            self.id_bytes, self.rank, self.world, self.device = bytes(id_bytes), int(rank), int(world), int(device)
+            self._h, self._keep = None, []
+            dist.barrier()
+
+        @staticmethod
+        def unique_id():
+            return os.urandom(ocomm.ID_BYTES)
+
+        @staticmethod
+        def _set_device(device):
+            pass
+
+        def all_reduce_scalar(self, value, op=ocomm.AVG):
+            t = torch.tensor([value], dtype=torch.float64)
+            dist.all_reduce(t, op={ocomm.SUM: dist.ReduceOp.SUM, ocomm.AVG: dist.ReduceOp.SUM, ocomm.MAX: dist.ReduceOp.MAX}[op])
+            return float(t.item()) / (self.world if op == ocomm.AVG else 1)
+
+        def barrier(self):
+            dist.barrier()
+
+        def destroy(self):
+            pass
+    return GlooComm
+
+
+def _bench_control_worker(rank, world, port, fail_rank, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from octcubem_amd import comm as ocomm
+    assert bench.MAX_OP == ocomm.MAX
+    Comm = _fake_comm_class()
+    store = dist.distributed_c10d._get_default_store()
+    comm = bench.bring_up_native_comm(store, rank, world, 0, Comm, fail_rank=fail_rank, poll=0.1, timeout=60.0)
+    res = {"rank": rank, "world_seen": int(round(comm.all_reduce_scalar(1.0, ocomm.SUM)))}
+    # every rank holds the id rank 0 published (MAX and MIN of a digest agree with the rank's own)
+    digest = float(int.from_bytes(comm.id_bytes[:6], "little"))
+    res["same_id"] = bench.max_over_ranks(comm, digest) == digest and -bench.max_over_ranks(comm, -digest) == digest
+    res["agree_none"] = bench.agree_any(comm, False)
+    res["agree_one"] = bench.agree_any(comm, rank == 3)               # one rank ran out of memory: everybody falls back
+    res["max"] = bench.max_over_ranks(comm, 1.5 * rank)               # step time / exposed-communication MAX
+    # a second communicator on the same store (generation 1) must not read the first one's id
+    comm2 = Comm.from_store(store, rank, world, 0)
+    res["new_generation_new_id"] = comm2.id_bytes != comm.id_bytes
+    d2 = float(int.from_bytes(comm2.id_bytes[:6], "little"))
+    res["same_id2"] = bench.max_over_ranks(comm2, d2) == d2
+    q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_bench_control_plane_with_a_fake_communicator_world8():
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_control_worker, args=(r, world, port, None, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=200) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(r["rank"] for r in res) == list(range(world))
+    for r in res:
+        assert r["world_seen"] == world and r["same_id"] and r["same_id2"] and r["new_generation_new_id"], r
+        assert r["agree_none"] is False and r["agree_one"] is True and r["max"] == 1.5 * (world - 1), r
+
+
+@pytest.mark.timeout(240)
+def test_every_rank_exits_3_when_one_rank_cannot_create_its_communicator_world8():
+    """Rank 5's creation fails; the other seven sit inside the collective creation (the stand-in's barrier) -- only the watchdog thread
+    can end them.  Every process must exit with status 3, promptly."""
+    import time
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_control_worker, args=(r, world, port, 5, q)) for r in range(world)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert [p.exitcode for p in procs] == [3] * world, [p.exitcode for p in procs]
+    assert time.time() - t0 < 110
+    assert q.empty()

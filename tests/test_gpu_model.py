@@ -310,6 +310,49 @@ def test_full_size_properties_batch2():
     assert rel(p1, pred[1:].detach()) <= 1e-2 and rel(p1, p1u) <= 1e-2          # measured 3.7e-3
 
 
+def test_operand_copy_guard_catches_a_write_behind_the_version_counters(golden_dir):
+    """The arena re-casts its 16-bit operand copy only when a parameter's PyTorch version counter moved (arena.refresh_lp).  A write
+    no counter sees -- ``p.data.mul_()`` here; ``dist.broadcast(p.data)`` or an EMA swap through ``.data`` in the wild -- leaves the
+    MFMA operands stale WITHOUT an error; the documented remedy is model.invalidate_lp(), and the sampled guard must
+    notice a forgotten call, warn and repair.  Also: after FusedAdamW steps the copy its kernel wrote equals the cast of the master
+    weights exactly (the guard raises no false alarm in a training loop)."""
+    import warnings
+    from octcubem_amd import arena as A
+    z, cfg, P = small(golden_dir)
+    m = build(cfg, P).train()
+    imgs, noise = torch.from_numpy(z["imgs"]).to(DEV), torch.from_numpy(z["noise"]).to(DEV)
+    opt = foptim.FusedAdamW(misc.add_weight_decay(m, 0.05), lr=1e-3, betas=(0.9, 0.95))
+    scaler = misc.NativeScalerWithGradNormCount(fp32=True)
+    prev, A.CHECK_LP_EVERY = A.CHECK_LP_EVERY, 1                    # check at every skipped refresh
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)          # three optimizer steps: never a (false) alarm
+            for _ in range(3):
+                opt.zero_grad()
+                loss, _, _ = m(imgs, mask_ratio=0.75, noise=noise)
+                scaler(loss, opt, parameters=m.parameters())
+            assert m.arena.lp_matches()
+            with torch.no_grad():
+                ref_loss, _, _ = m(imgs, mask_ratio=0.75, noise=noise)
+        v0 = m.decoder_pred.weight._version
+        m.decoder_pred.weight.data.mul_(2.0)                        # behind the version counter
+        assert m.decoder_pred.weight._version == v0 and not m.arena.lp_matches()
+        with pytest.warns(RuntimeWarning, match="operand copy"), torch.no_grad():
+            m(imgs, mask_ratio=0.75, noise=noise)                   # the guard notices, warns, re-casts
+        assert m.arena.lp_matches()
+        with torch.no_grad():
+            loss2, _, _ = m(imgs, mask_ratio=0.75, noise=noise)
+        assert abs(float(loss2) - float(ref_loss)) > 1e-3 * float(ref_loss)          # the doubled weights are in use now
+        m.decoder_pred.weight.data.mul_(0.5)                        # the documented way: say so
+        m.invalidate_lp()
+        with warnings.catch_warnings(), torch.no_grad():
+            warnings.simplefilter("error", RuntimeWarning)
+            loss3, _, _ = m(imgs, mask_ratio=0.75, noise=noise)
+        assert float(loss3) == float(ref_loss)
+    finally:
+        A.CHECK_LP_EVERY = prev
+
+
 def test_fused_block_backward_with_shared_activation():
     """BlockFn hands the bf16 copy / column sums of its input gradient to the upstream Block through a side channel that
     is only valid when autograd delivers that very tensor.  Here the first Block's output feeds BOTH the second Block and

@@ -1,6 +1,6 @@
 """A kernel-selection option on / off for the forward / dgrad GEMM shapes of one ViT-L encoder / decoder Block at a given number of
 volumes per micro-batch (same process, interleaved, random operands).
-usage: python tools/gemm_option_ab.py <option, e.g. gemm_wave128 | gemm_mfma16> [volumes ...]"""
+usage: python tools/gemm_option_ab.py <option, e.g. gemm_small> [volumes ...]"""
 import sys
 import time
 

@@ -65,18 +65,13 @@ def main():
         bias = torch.zeros(4 * C, device="cuda")
         gw = torch.zeros(4 * C, C, device="cuda")
         fl = 2.0 * M * C * 4 * C
-        for m16 in (0, 1):
-            ops.set_option("gemm_mfma16", m16)
-            tag = "16x16x32" if m16 else "32x32x16 (shipped)"
-            measure(f"gemm fwd fc1 bf16 out, {vols} vol, {tag}", lambda: ops.linear_fwd(x, w1, bias, "bf16"), fl)
-            measure(f"gemm dgrad fc1, {vols} vol, {tag}", lambda: ops.linear_dgrad(x4, w1), fl)
-        ops.set_option("gemm_mfma16", 0)
+        measure(f"gemm fwd fc1 bf16 out, {vols} vol", lambda: ops.linear_fwd(x, w1, bias, "bf16"), fl)
+        measure(f"gemm dgrad fc1, {vols} vol", lambda: ops.linear_dgrad(x4, w1), fl)
         measure(f"gemm wgrad fc1, {vols} vol", lambda: ops.linear_wgrad_accum(x4, x, gw), fl)
-        for sk in (False, True):
-            ops.STREAMK = sk
-            measure(f"gemm fwd fc2 + residual, {vols} vol, {'stream-K' if sk else 'plain (shipped)'}",
-                    lambda: ops.linear_fwd(x4, w2, bias[:C], "resid", res=res), fl)
-        ops.STREAMK = False
+        for force, tag in ((-1, "256-tile (shipped at this size)"), (2, "small-launch kernel, 2-stage ring")):
+            ops.FORCE_SMALL_LAUNCH = force
+            measure(f"gemm fwd fc2 + residual, {vols} vol, {tag}", lambda: ops.linear_fwd(x4, w2, bias[:C], "resid", res=res), fl)
+        ops.FORCE_SMALL_LAUNCH = 0
         del x, x4, w1, w2, res, gw
     xf = torch.randn(128 * 1281, 1024, device="cuda", generator=g); gm = torch.ones(1024, device="cuda"); bt = torch.zeros(1024, device="cuda")
     measure("layernorm fwd D 1024 (bandwidth-bound)", lambda: ops.layernorm_fwd(xf, gm, bt, 1e-6))
