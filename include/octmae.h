@@ -51,8 +51,10 @@ int octmae_lp_dtype(void);
  *                          csrc/gemm.hip (plan128) prices it faster; 0: never (the choice before round 6).  Bits 12 / 13 (0x1000 /
  *                          0x2000) of octmae_gemm_bf16's `epilogue` argument force that kernel with a 4- / 2-stage ring for one
  *                          call (its k split is then `splitk`, 1 .. 4), bit 14 (0x4000) forbids it (bits 8-10: the other variants)
- *   "gemm_small_launches", "gemm_small_split_launches"   read-only: how many GEMM launches of this process took that kernel / took
- *                          it with a k split (tests)
+ *   "gemm_small_launches", "gemm_small_split_launches", "gemm_small_wgrad_launches"   read-only: how many GEMM launches of this process
+ *                          took that kernel / took it with a k split / how many weight-gradient pairs took its 128-tile form (tests)
+ *   "wgrad_s1_atomic"      the epilogue of an UNSPLIT weight-gradient launch: 2 (default) read-modify-write in batches of 16 registers
+ *                          through a buffer descriptor, 1 the fp32 atomics of a split launch, 0 one guarded load + store per register
  *   "wgrad_stagger"        v >= 0 (default 29): split-K weight gradients of >= 8 slices with <= 96 k-tiles each run with slice
  *                          lengths rising by v / 256 k-tiles per output tile of the launch from one slice to the next, so that the
  *                          slices' fp32-atomic epilogues follow one another instead of colliding; 0: equal slices */
@@ -115,8 +117,10 @@ int octmae_linear_dgrad_dgelu(const void* W, const void* dY, void* dX, const voi
  *   gW0 f32 [N0][K0] += dY0[M][N0]^T @ X0[M][K0],   gW1 f32 [N1][K1] += dY1[M][N1]^T @ X1[M][K1]      (dY, X bf16, row-major)
  *   gB0 / gB1: NULL, or f32 [N] += the column sums of dY (the bias gradient, as epilogue 5 of octmae_gemm_bf16 with C2)
  * The output tiles of both problems share one split over M: half the fp32-atomic epilogues of two separate launches and k-loops
- * twice as long.  splitk as in octmae_gemm_bf16.  Returns -2 when either problem does not take the 256-tile kernel (N or K < 256,
- * an operand beyond a 32-bit buffer range): the caller then issues two octmae_gemm_bf16 calls. */
+ * twice as long.  splitk as in octmae_gemm_bf16.  Short reductions on few tiles (one or two volumes per step: M <= 96 k-tiles of 64 rows)
+ * run on 128 x 128 tiles instead when the cost model of csrc/gemm.hip prices that faster ("gemm_small"; gB is then a launch of its own).
+ * Returns -2 when either problem does not take the 256-tile kernel (N or K < 256, an operand beyond a 32-bit buffer range): the
+ * caller then issues two octmae_gemm_bf16 calls. */
 int octmae_wgrad_accum_pair(const void* dY0, const void* X0, float* gW0, float* gB0, int N0, int K0, int ldy0, int ldx0, int ldw0,
                             const void* dY1, const void* X1, float* gW1, float* gB1, int N1, int K1, int ldy1, int ldx1, int ldw1,
                             int M, int splitk, void* stream);

@@ -820,7 +820,7 @@ std::atomic<int> g_attn_bwd_tail_fused{1};      // the single-key tail inside th
 extern std::atomic<int> g_wgrad_stagger;    // defined in gemm.hip: staggered split-K slices of the weight-gradient kernel
 extern std::atomic<int> g_wgrad_s1_atomic;  // defined in gemm.hip: fp32 atomics in the epilogue of an unsplit weight-gradient launch
 extern std::atomic<int> g_gemm_small;       // defined in gemm.hip: the small-launch kernel (gemm128d_kernel) where the cost model picks it
-extern std::atomic<int> g_small_launches, g_small_split_launches;
+extern std::atomic<int> g_small_launches, g_small_split_launches, g_small_wgrad_launches;
 std::atomic<int> g_attn_bwd_hd32_form{1};
 std::atomic<int> g_attn_bwd_hd64_form{1};
 
@@ -896,6 +896,7 @@ extern "C" int octmae_set_option(const char* key, int value) {
   if (__builtin_strcmp(key, "gemm_small") == 0) return g_gemm_small.exchange(value ? 1 : 0);      // csrc/gemm.hip
   if (__builtin_strcmp(key, "gemm_small_launches") == 0) return g_small_launches.load();      // read-only counters (tests)
   if (__builtin_strcmp(key, "gemm_small_split_launches") == 0) return g_small_split_launches.load();
+  if (__builtin_strcmp(key, "gemm_small_wgrad_launches") == 0) return g_small_wgrad_launches.load();
   return -1;
 }
 

@@ -1020,29 +1020,21 @@ constexpr int T1 = 128;
 constexpr int D_STAGE = 2 * TILE_BYTES;      // 32 KiB: A image | B image
 constexpr int D_SLOT_FLOATS = T1 * T1;
 
-template <bool A_KS, bool B_KS, int EPI, int NST>
-__global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm128d_kernel(const GemmParams p, const SplitWs w, const int S) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ unsigned s_arrival;
+// main loop of the small-launch kernels: tile t of p, k slice kz of S -> acc (the wave's 64 x 64 block at a0 + wa 64, b0 + wb 64);
+// returns with every ring request retired and a workgroup barrier passed (the LDS is free for the epilogue)
+template <bool A_KS, bool B_KS, int NST>
+__device__ __forceinline__ void gemm128d_mainloop(const GemmParams& p, const int t, const int kz, const int S, char* smem,
+                                                  f32x16 (&acc)[2][2], int& a0, int& b0) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wid >> 1, wb = wid & 1;
-  const int nt = p.tiles_a * p.tiles_b;
-  int t, kz;
-  if (S > 1) {      // k-slice-major over the XCD-contiguous index, as the weight gradients: an XCD's workgroups share panels
-    const int L = xcd_remap((int)blockIdx.x, nt * S);
-    kz = L / nt; t = L - kz * nt;
-  } else {
-    t = xcd_remap((int)blockIdx.x, nt); kz = 0;
-  }
   int ta, tb;
   tile_coord(p, t, ta, tb);
-  const int a0 = ta * T1, b0 = tb * T1;
+  a0 = ta * T1; b0 = tb * T1;
   int kt0, kt1;
   split_range(p, kz, S, kt0, kt1);
   const int nk = kt1 - kt0;
 
-  f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1125,6 +1117,27 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm128d_kernel(const G
     __builtin_amdgcn_s_barrier();
   }
 
+}
+
+template <bool A_KS, bool B_KS, int EPI, int NST>
+__global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm128d_kernel(const GemmParams p, const SplitWs w, const int S) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ unsigned s_arrival;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wa = wid >> 1, wb = wid & 1;
+  const int nt = p.tiles_a * p.tiles_b;
+  int t, kz;
+  if (S > 1) {      // k-slice-major over the XCD-contiguous index, as the weight gradients: an XCD's workgroups share panels
+    const int L = xcd_remap((int)blockIdx.x, nt * S);
+    kz = L / nt; t = L - kz * nt;
+  } else {
+    t = xcd_remap((int)blockIdx.x, nt); kz = 0;
+  }
+  f32x16 acc[2][2];
+  int a0, b0;
+  gemm128d_mainloop<A_KS, B_KS, NST>(p, t, kz, S, smem, acc, a0, b0);
+
   if (S > 1) {
     {   // publish this slice's partial tile: lane-contiguous 16-byte write-through stores, 4 KiB per store instruction
       const unsigned long long q = reinterpret_cast<unsigned long long>(w.slots) + ((unsigned long long)t * S + kz) * (D_SLOT_FLOATS * 4);
@@ -1181,6 +1194,33 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm128d_kernel(const G
 }
 
 
+// The weight gradients of a small launch (round 6): the pair kernel above on 128 x 128 tiles -- the main loop of gemm128d_kernel with
+// both operands k-strided, the fp32-accumulating OUT_AB epilogue (atomics when the k range is split, batched read-modify-write
+// otherwise).  One volume per step gives the fc1 + fc2 pair 128 tiles of 256 x 256 over 21 k-tiles: half the CUs for 40 us; here
+// 512 workgroups of a quarter the work, two per CU.  The bias gradient (column sums of dY) is a separate launch on this path.
+template <int NST>
+__global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm128d_wgrad_kernel(const GemmPair pp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wa = wid >> 1, wb = wid & 1;
+  const int nt = pp.nt0 + pp.nt1;
+  const int L = xcd_remap((int)blockIdx.x, nt * pp.S);          // k-slice-major
+  const int kz = L / nt;
+  int t = L - kz * nt;
+  const bool second = t >= pp.nt0;                              // workgroup-uniform
+  if (second) t -= pp.nt0;
+  f32x16 acc[2][2];
+  int a0, b0;
+  if (!second) {
+    gemm128d_mainloop<true, true, NST>(pp.p0, t, kz, pp.S, smem, acc, a0, b0);
+    gemm_epilogue<EPI_ACCUM, true, 2, 2>(pp.p0, acc, a0 + wa * 64, b0 + wb * 64, lane, pp.S > 1 || pp.p0.atomic1 == 1);
+  } else {
+    gemm128d_mainloop<true, true, NST>(pp.p1, t, kz, pp.S, smem, acc, a0, b0);
+    gemm_epilogue<EPI_ACCUM, true, 2, 2>(pp.p1, acc, a0 + wa * 64, b0 + wb * 64, lane, pp.S > 1 || pp.p1.atomic1 == 1);
+  }
+}
+
 // Staggered split-K slices of the 256-tile weight-gradient kernel (split_range): v = the length step between neighbouring slices in
 // 1/256 k-tiles PER OUTPUT TILE of the launch (the atomic time of a slice grows with its tile count: 256 KiB at 1.35 TB/s = 0.19 us
 // per tile against 1.7 us per k-tile, i.e. v = 29); 0 = equal slices.  octmae_set_option("wgrad_stagger", v) / OCTMAE_WGRAD_STAGGER.
@@ -1225,6 +1265,7 @@ static long long d_ws_bytes() { return (long long)D_WS_SLOTS * D_SLOT_FLOATS * 4
 std::atomic<int> g_gemm_small{1};          // octmae_set_option("gemm_small", 0 / 1); OCTMAE_GEMM_SMALL overrides
 std::atomic<int> g_small_launches{0};      // how many launches took gemm128d_kernel ("gemm_small_launches": tests)
 std::atomic<int> g_small_split_launches{0};
+std::atomic<int> g_small_wgrad_launches{0};   // weight-gradient pairs that took gemm128d_wgrad_kernel ("gemm_small_wgrad_launches")
 
 struct Plan128 {
   int use;      // 1: gemm128d_kernel
@@ -1542,9 +1583,62 @@ extern "C" int octmae_wgrad_accum_pair(const void* dY0, const void* X0, float* g
   pp.p0.ktiles_per_split = pp.p1.ktiles_per_split = per;
   pp.nt0 = pp.p0.tiles_a * pp.p0.tiles_b; pp.nt1 = pp.p1.tiles_a * pp.p1.tiles_b; pp.S = splitk;
   pp.p0.kstagger = pp.p1.kstagger = wgrad_stagger_for(ktiles, splitk, pp.nt0 + pp.nt1);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // Small launches (round 6): 128 x 128 tiles when the cost model prices them faster.  Microseconds, fitted with tools/gemm_small_fit.py:
+  // the 256-tile pair ~1.4 per k-tile of a slice + 0.22 per tile and slice of fp32 atomics (split) or ~10 of read-modify-write
+  // (unsplit); a 128-tile workgroup (both operands through transposing LDS reads) ~0.6 per k-tile alone on its CU (4-stage ring), ~1.05
+  // two per CU (2-stage), + ~8, + 0.055 per tile and slice of atomics.  Measured (profiles/r06_gemm_small_fit.txt): one volume, encoder
+  // fc pair 40 -> 32 us, qkv + proj 40 -> 26, decoder 52 -> 39 and 40 -> 32; four volumes 113 -> 90 and 77 -> 64.  Short reductions only
+  // (<= 96 k-tiles per launch): beyond, both kernels stream and the larger tile wins.
+  {
+    static const int env = getenv("OCTMAE_GEMM_SMALL") ? atoi(getenv("OCTMAE_GEMM_SMALL")) : -1;
+    const int on = env >= 0 ? env : g_gemm_small.load(std::memory_order_relaxed);
+    const int G = device_cus();
+    const long long nt128_0 = (long long)((N0 + T1 - 1) / T1) * ((K0 + T1 - 1) / T1), nt128_1 = (long long)((N1 + T1 - 1) / T1) * ((K1 + T1 - 1) / T1);
+    const long long nt128 = nt128_0 + nt128_1;
+    static const int maxkt = getenv("OCTMAE_WGRAD128_MAXKT") ? atoi(getenv("OCTMAE_WGRAD128_MAXKT")) : 96;      // A/B runs
+    if (on && ktiles <= maxkt && nt128 <= 2 * G) {
+      const double c256 = 1.4 * per + (splitk > 1 ? 0.22 * (pp.nt0 + pp.nt1) * splitk : 10.0);
+      double best = 1e30;
+      int bS = 1, bN = 4;
+      for (int S2 = 1; S2 <= 4 && S2 <= splitk; ++S2) {        // never more slices than the caller allows (splitk = 1: no atomics)
+        const int kper = (ktiles + S2 - 1) / S2;
+        if (S2 > 1 && (kper < 8 || (long long)(S2 - 1) * kper >= ktiles)) continue;
+        const long long wg = nt128 * S2;
+        const double at = S2 > 1 ? 0.055 * nt128 * S2 : 0.0;
+        if (wg <= G && 0.6 * kper + 8.0 + at < best) { best = 0.6 * kper + 8.0 + at; bS = S2; bN = 4; }
+        if (wg > G && wg <= 2 * G && 1.05 * kper + 8.0 + at < best) { best = 1.05 * kper + 8.0 + at; bS = S2; bN = 2; }
+      }
+      if (best < 0.9 * c256) {
+        auto to128 = [&](GemmParams& p, int N, int K) {
+          p.tiles_a = (N + T1 - 1) / T1; p.tiles_b = (K + T1 - 1) / T1; p.cgroup = p.tiles_a; p.kstagger = 0;
+          p.ktiles_per_split = (ktiles + bS - 1) / bS;
+        };
+        // the bias gradients ride in the 256-tile kernel's main loop; on this path they are a pass of their own over dY
+        if (gB0 != nullptr) { if (int rc = octmae_colsum_accum(dY0, 1, gB0, M, N0, ldy0, stream)) return rc; }
+        if (gB1 != nullptr) { if (int rc = octmae_colsum_accum(dY1, 1, gB1, M, N1, ldy1, stream)) return rc; }
+        pp.p0.C2 = nullptr; pp.p1.C2 = nullptr;
+        to128(pp.p0, N0, K0); to128(pp.p1, N1, K1);
+        pp.nt0 = (int)nt128_0; pp.nt1 = (int)nt128_1; pp.S = bS;
+        if (bN == 2) {
+          auto k2 = gemm128d_wgrad_kernel<2>;
+          static DynLdsOnce once2;
+          if (int rc = once2.ensure(reinterpret_cast<const void*>(k2), 2 * D_STAGE)) return rc;
+          hipLaunchKernelGGL(k2, dim3((unsigned)(nt128 * bS), 1, 1), dim3(256), 2 * D_STAGE, st, pp);
+        } else {
+          auto k4 = gemm128d_wgrad_kernel<4>;
+          static DynLdsOnce once4;
+          if (int rc = once4.ensure(reinterpret_cast<const void*>(k4), 4 * D_STAGE)) return rc;
+          hipLaunchKernelGGL(k4, dim3((unsigned)(nt128 * bS), 1, 1), dim3(256), 4 * D_STAGE, st, pp);
+        }
+        OCTMAE_LAUNCH_CHECK();
+        g_small_wgrad_launches.fetch_add(1, std::memory_order_relaxed);
+        return 0;
+      }
+    }
+  }
   auto kern = gemm256p_wgrad_pair_kernel;
   static DynLdsOnce once;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (int rc = once.ensure(reinterpret_cast<const void*>(kern), 4 * TILE2_BYTES)) return rc;
   hipLaunchKernelGGL(kern, dim3((pp.nt0 + pp.nt1) * splitk, 1, 1), dim3(512), 4 * TILE2_BYTES, st, pp);
   OCTMAE_LAUNCH_CHECK();

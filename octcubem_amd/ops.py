@@ -204,6 +204,12 @@ FORCE_SMALL_LAUNCH = 0      # tests / A-B: 4 or 2 = every forward / dgrad GEMM t
 FORCE_SPLITK = 1            #   FORCE_SPLITK, 1 .. 4); -1 = never that kernel (the pre-round-6 choice)
 
 
+# The fc1 forward's epilogue stores gelu'(pre) in place of pre and the fc2 dgrad's epilogue multiplies with it (VERDICT r05 item 3,
+# route i): one more 16-bit rounding point (gelu' itself), no transcendental in the backward epilogue.  bench.py --set
+# ops.GELU_PRIME_FWD=1 for the same-box A/B of the step; the flag a forward ran with travels with its saved tensor.
+GELU_PRIME_FWD = os.environ.get("OCTMAE_GELU_PRIME_FWD", "0") == "1"
+
+
 def _variant_bits():
     return (0x100 if FORCE_SMALL_TILE else 0) | (0x200 if FORCE_TWO_STAGE else 0) | (0x400 if FORCE_PHASED else 0) | \
         (0x1000 if FORCE_SMALL_LAUNCH == 4 else 0x2000 if FORCE_SMALL_LAUNCH == 2 else 0x4000 if FORCE_SMALL_LAUNCH < 0 else 0) | \
@@ -234,7 +240,7 @@ def _split_ws_for(st: int):
 
 def _gemm(A, B, C, NA, NB, K, lda, ldb, ldc, a_ks, b_ks, epi, C2=None, bias=None, aux=None, ldaux=0, splitk=1):
     st = _stream()
-    if epi != EPI_ACCUM and not FORCE_SMALL_TILE:   # forward / dgrad kinds: lend the split-K workspace
+    if (epi & 0xff) != EPI_ACCUM and not FORCE_SMALL_TILE:   # forward / dgrad kinds: lend the split-K workspace
         skp, skn = _split_ws_for(st)
         args = (A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(C2), _p(bias), _p(aux), NA, NB, K, lda, ldb, ldc, ldaux, a_ks, b_ks,
                 epi | _variant_bits(), FORCE_SPLITK if FORCE_SMALL_LAUNCH > 0 else splitk, skp, skn, st)
@@ -246,19 +252,20 @@ def _gemm(A, B, C, NA, NB, K, lda, ldb, ldc, a_ks, b_ks, epi, C2=None, bias=None
     if KTIMER is None:
         call(fn, *args)
     else:
-        kind = f"{_GEMM_KIND.get((a_ks, b_ks), 'gemm')}_epi{epi}"
+        kind = f"{_GEMM_KIND.get((a_ks, b_ks), 'gemm')}_epi{epi & 0xff}"
         # algorithmic bytes: both operands once, the output, the second output of the GELU epilogue (2), the residual (3) or
         # pre-activation (4) the epilogue reads
         nbytes = 2.0 * (NA * K + NB * K) + C.element_size() * NA * NB
-        if epi == 2 and C2 is not None:
+        if (epi & 0xff) == 2 and C2 is not None:
             nbytes += C2.element_size() * NA * NB
-        if epi in (3, 4) and aux is not None:
+        if (epi & 0xff) in (3, 4) and aux is not None:
             nbytes += aux.element_size() * NA * NB
         KTIMER.launch(kind, 2.0 * NA * NB * K, nbytes, lambda: call(fn, *args))
 
 
 def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mode: str = "bf16",
-               res: Optional[torch.Tensor] = None, rowscale: Optional[torch.Tensor] = None, rows_per_scale: int = 1):
+               res: Optional[torch.Tensor] = None, rowscale: Optional[torch.Tensor] = None, rows_per_scale: int = 1,
+               store_dgelu: bool = False):
     """y = x @ w.T + bias.  x bf16 [M,K], w bf16 [N,K], bias f32 [N].
     mode: 'bf16' | 'f32' | 'gelu' (returns (pre, act)) | 'resid' (f32: res + y, or res + rowscale[m // rows_per_scale] * y)."""
     M, K = x.shape
@@ -284,7 +291,8 @@ def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], m
     if mode == "gelu":
         pre = torch.empty((M, N), dtype=BF16, device=dev)
         act = torch.empty((M, N), dtype=BF16, device=dev)
-        _gemm(w, x, pre, N, M, K, w.stride(0), x.stride(0), N, 0, 0, EPI_GELU, C2=act, bias=bias)
+        # store_dgelu: `pre` receives gelu'(pre-activation) -- what linear_dgrad(..., pre_is_dgelu=True) multiplies with
+        _gemm(w, x, pre, N, M, K, w.stride(0), x.stride(0), N, 0, 0, EPI_GELU | (0x8000 if store_dgelu else 0), C2=act, bias=bias)
         return pre, act
     if mode == "resid":
         out = torch.empty((M, N), dtype=F32, device=dev)
@@ -294,7 +302,7 @@ def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], m
 
 
 def linear_dgrad(dy: torch.Tensor, w: torch.Tensor, pre: Optional[torch.Tensor] = None,
-                 colsum: Optional[torch.Tensor] = None, atomic_colsum: bool = False) -> torch.Tensor:
+                 colsum: Optional[torch.Tensor] = None, atomic_colsum: bool = False, pre_is_dgelu: bool = False) -> torch.Tensor:
     """dx[M,K] = dy[M,N] @ w[N,K]  (optionally * gelu'(pre[M,K])), bf16.  With ``pre``, ``colsum`` (fp32 [K]) receives
     += the column sums of dx -- the bias gradient of the Linear that produced ``pre`` -- from the same call: per-slab partial
     sums through a workspace and a folding launch (octmae_linear_dgrad_dgelu); ``atomic_colsum`` selects the
@@ -306,13 +314,14 @@ def linear_dgrad(dy: torch.Tensor, w: torch.Tensor, pre: Optional[torch.Tensor] 
         assert colsum is None
         _gemm(w, dy, dx, K, M, N, w.stride(0), dy.stride(0), K, 1, 0, EPI_BF16)
     elif colsum is None or atomic_colsum:
-        _gemm(w, dy, dx, K, M, N, w.stride(0), dy.stride(0), K, 1, 0, EPI_DGELU, C2=colsum, aux=pre, ldaux=pre.stride(0))
+        _gemm(w, dy, dx, K, M, N, w.stride(0), dy.stride(0), K, 1, 0, EPI_DGELU | (0x8000 if pre_is_dgelu else 0), C2=colsum, aux=pre,
+              ldaux=pre.stride(0))
     else:
         rows = load().octmae_dgelu_colsum_ws_rows(M)
         ws = torch.empty((rows, K), dtype=F32, device=dy.device)
         st = _stream()
         args = (w.data_ptr(), dy.data_ptr(), dx.data_ptr(), pre.data_ptr(), ws.data_ptr(), colsum.data_ptr(), M, N, K, w.stride(0),
-                dy.stride(0), K, pre.stride(0), _variant_bits(), *_split_ws_for(st), st)
+                dy.stride(0), K, pre.stride(0), _variant_bits() | (0x8000 if pre_is_dgelu else 0), *_split_ws_for(st), st)
         if KTIMER is None:
             call("octmae_linear_dgrad_dgelu", *args)
         else:   # two launches (GEMM + the fold of the partial sums), timed together
@@ -697,7 +706,8 @@ class MlpFn(torch.autograd.Function):
         shp = y.shape
         Cc = shp[-1]
         y2 = cast_bf16(y.reshape(-1, Cc))
-        pre, act = linear_fwd(y2, w1_lp, b1_32, "gelu")
+        ctx.pre_is_dgelu = GELU_PRIME_FWD
+        pre, act = linear_fwd(y2, w1_lp, b1_32, "gelu", store_dgelu=ctx.pre_is_dgelu)
         if res is not None:
             out = linear_fwd(act, w2_lp, b2_32, "resid", res=_chk(res.reshape(-1, Cc), F32, "residual"))
         else:
@@ -718,7 +728,7 @@ class MlpFn(torch.autograd.Function):
         if gb2 is not None:
             colsum_accum(d2, gb2)
         linear_wgrad_accum(dob, act, gw2)
-        dpre = linear_dgrad(dob, w2_lp, pre=pre, colsum=gb1)
+        dpre = linear_dgrad(dob, w2_lp, pre=pre, colsum=gb1, pre_is_dgelu=ctx.pre_is_dgelu)
         linear_wgrad_accum(dpre, y2, gw1)
         notify_grad_ready(ctx.params)
         dy = linear_dgrad(dpre, w1_lp).view(ctx.shp)
@@ -788,7 +798,8 @@ class BlockFn(torch.autograd.Function):
         o, lse = attn_fwd(qkv, Bn, N, H, HD, scale)
         x2 = linear_fwd(o, wproj, bproj, "resid", res=x2d, rowscale=s1, rows_per_scale=N)
         y2, mean2, rstd2 = layernorm_fwd(x2, g2, be2, eps2)
-        pre, act = linear_fwd(y2, w1, b1, "gelu")
+        ctx.pre_is_dgelu = GELU_PRIME_FWD
+        pre, act = linear_fwd(y2, w1, b1, "gelu", store_dgelu=ctx.pre_is_dgelu)
         if final_residual:
             x3 = linear_fwd(act, w2, b2, "resid", res=x2, rowscale=s2, rows_per_scale=N)
         else:
@@ -827,7 +838,7 @@ class BlockFn(torch.autograd.Function):
             if gb2 is not None:
                 colsum_accum(d3, gb2)
         # ---- MLP
-        dpre = linear_dgrad(d3b, w2, pre=pre, colsum=gb1)          # GELU' and fc1's bias gradient in the epilogue
+        dpre = linear_dgrad(d3b, w2, pre=pre, colsum=gb1, pre_is_dgelu=ctx.pre_is_dgelu)          # GELU' and fc1's bias gradient in the epilogue
         linear_wgrad_accum_pair((d3b, act, gw2, None), (dpre, y2, gw1, None))
         dy2 = linear_dgrad(dpre, w1)
         # ---- LN2 backward + residual add + bf16 copy + proj bias gradient

@@ -205,3 +205,38 @@ def test_without_the_workspace_nothing_is_split():
     finally:
         ops.set_option("gemm_small", prev)
     assert rel(y2, y) < 1e-6
+
+
+# (M, D): the weight-gradient pairs of ONE and TWO volumes -- fc2 + fc1 and proj + qkv of an encoder Block (D 1024) and a decoder Block (D 512)
+@pytest.mark.parametrize("M,D,taken", [(1281, 1024, True), (2562, 1024, True), (5121, 512, True), (32 * 1281, 1024, False)])
+def test_small_launch_weight_gradient_pairs(M, D, taken):
+    """octmae_wgrad_accum_pair on 128 x 128 tiles (gemm128d_wgrad_kernel) where the cost model takes it -- short reductions on few
+    tiles --: both gradients of both pairs against an fp64 product on top of a non-zero accumulator, the qkv bias gradient (a launch
+    of its own on this path), twice in a row (accumulation), and the same numbers as the 256-tile pair kernel to fp32 rounding."""
+    g = torch.Generator().manual_seed(M + D)
+    y1 = bf(torch.randn(M, D, generator=g)).to(DEV); act = bf(torch.randn(M, 4 * D, generator=g)).to(DEV)
+    dpre = bf(torch.randn(M, 4 * D, generator=g)).to(DEV); o = bf(torch.randn(M, D, generator=g)).to(DEV)
+    dqkv = bf(torch.randn(M, 3 * D, generator=g)).to(DEV); d3 = bf(torch.randn(M, D, generator=g)).to(DEV)
+
+    def run():
+        gw2 = torch.ones(D, 4 * D, device=DEV); gw1 = torch.ones(4 * D, D, device=DEV)
+        gwp = torch.ones(D, D, device=DEV); gwq = torch.ones(3 * D, D, device=DEV); gbq = torch.ones(3 * D, device=DEV)
+        for _ in range(2):
+            ops.linear_wgrad_accum_pair((d3, act, gw2, None), (dpre, y1, gw1, None))
+            ops.linear_wgrad_accum_pair((d3, o, gwp, None), (dqkv, y1, gwq, gbq))
+        return gw2, gw1, gwp, gwq, gbq
+
+    n0 = ops.set_option("gemm_small_wgrad_launches", 0)
+    got = run()
+    n1 = ops.set_option("gemm_small_wgrad_launches", 0)
+    assert n1 - n0 == (4 if taken else 0), (n0, n1)
+    prev = ops.set_option("gemm_small", 0)
+    try:
+        ref = run()
+        assert ops.set_option("gemm_small_wgrad_launches", 0) == n1
+    finally:
+        ops.set_option("gemm_small", prev)
+    exact = (1 + 2 * d3.double().t() @ act.double(), 1 + 2 * dpre.double().t() @ y1.double(), 1 + 2 * d3.double().t() @ o.double(),
+             1 + 2 * dqkv.double().t() @ y1.double(), 1 + 2 * dqkv.double().sum(0))
+    for a_, r_, e_ in zip(got, ref, exact):
+        assert rel(a_, e_) < 1e-5 and rel(a_, r_) < 2e-6

@@ -211,6 +211,36 @@ def test_gemm_dgrad_and_wgrad(M, N, K, tile_variant):
     assert rel(gw3, gw_ref) < 1e-5 and rel(gb3, gb_ref) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(1281, 512, 256), (600, 4096, 256), (130, 768, 512), (2562, 1024, 1024)])
+def test_stored_gelu_prime_epilogues(M, N, K, tile_variant):
+    """ops.GELU_PRIME_FWD (variant bit 15 of the GEMM entry points): the fc1 forward stores gelu'(pre) -- of the 16-bit-rounded
+    pre-activation, rounded once more -- where it otherwise stores pre, and the fc2 dgrad multiplies with the stored value instead of
+    evaluating gelu' itself.  Same activation output bit for bit; the backward differs from the default form by that one rounding."""
+    g = torch.Generator().manual_seed(M + 5 * N)
+    x = bf(torch.randn(M, K, generator=g)).to(DEV)
+    w = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    pre, act = ops.linear_fwd(x, w, b, "gelu")
+    dg, act2 = ops.linear_fwd(x, w, b, "gelu", store_dgelu=True)
+    assert torch.equal(act, act2)
+    xg = pre.double().requires_grad_(True)
+    torch.nn.functional.gelu(xg).sum().backward()
+    assert rel(dg, xg.grad) < 3e-3 and float((dg.double() - xg.grad).abs().max()) <= 2.0 ** -8 + 1e-6      # gelu' in (-0.13, 1.13): one rounding
+    dy = bf(torch.randn(M, N, generator=g)).to(DEV)
+    pre_k = bf(torch.randn(M, K, generator=g)).to(DEV)              # pre-activation of the Linear being differentiated (K columns)
+    pk = pre_k.double().requires_grad_(True)
+    torch.nn.functional.gelu(pk).sum().backward()
+    stored = bf(pk.grad.float())
+    cs_a, cs_b = torch.zeros(K, device=DEV), torch.zeros(K, device=DEV)
+    dx_a = ops.linear_dgrad(dy, w, pre=pre_k, colsum=cs_a)
+    dx_b = ops.linear_dgrad(dy, w, pre=stored, colsum=cs_b, pre_is_dgelu=True)
+    exact = (dy.double() @ w.double()) * pk.grad
+    assert rel(dx_a, exact) < 4e-3 and rel(dx_b, exact) < 5e-3 and rel(dx_b, dx_a) < 4e-3
+    assert rel(cs_b, dx_b.double().sum(0)) < 2e-5 and rel(cs_b, cs_a) < 4e-3
+    dx_c = ops.linear_dgrad(dy, w, pre=stored, pre_is_dgelu=True)   # octmae_gemm_bf16's epilogue 4 without the column sums
+    assert torch.equal(dx_c, dx_b)
+
+
 @pytest.mark.parametrize("N,K,M", [(4096, 1024, 1500), (2048, 1280, 900), (1536, 2304, 700), (3072, 1024, 2000)])
 def test_wgrad_large_weight_tile_orders(N, K, M, tile_variant):
     """Weight gradients whose [N x K] output has more than 32 tiles of 256 x 256 take the k-slice-major, column-grouped
@@ -289,10 +319,14 @@ def _pair_call(probs, M, splitk):
     return load().octmae_wgrad_accum_pair(*args, M, splitk, torch.cuda.current_stream().cuda_stream)
 
 
+@pytest.mark.parametrize("small", [0, 1])
 @pytest.mark.parametrize("M", [64 * 21 + 9, 64 * 64])
-def test_wgrad_pair_is_bit_identical_to_single_launches_without_split(M):
+def test_wgrad_pair_is_bit_identical_to_single_launches_without_split(M, small):
     """Without a split there are no atomics: the pair kernel runs the same tile body (gemm256p_body) on the same k order, so each of
-    its two results must equal the single launch's bit for bit -- also for the bias-gradient column sums of a one-column-tile problem."""
+    its two results must equal the single launch's bit for bit -- also for the bias-gradient column sums of a one-column-tile problem.
+    small = 1: the pair may take its 128-tile form (gemm128d_wgrad_kernel: short reductions on few tiles) -- never with more slices
+    than the caller allows, so the weight gradients are still those bits (same k order per element); the bias gradient is then a
+    separate column-sum launch (another order of the same additions)."""
     g = torch.Generator().manual_seed(M)
     probs = []
     for N, K in ((768, 256), (256, 512)):
@@ -303,10 +337,17 @@ def test_wgrad_pair_is_bit_identical_to_single_launches_without_split(M):
         gw1 = gw.clone(); gb1 = gb.clone()
         ops._gemm(dy, x, gw1, dy.shape[1], x.shape[1], M, dy.stride(0), x.stride(0), gw1.stride(0), 1, 1, ops.EPI_ACCUM, C2=gb1, splitk=1)
         single.append((gw1, gb1))
-    assert _pair_call(probs, M, 1) == 0
+    prev = ops.set_option("gemm_small", small)
+    try:
+        n0 = ops.set_option("gemm_small_wgrad_launches", 0)
+        assert _pair_call(probs, M, 1) == 0
+        took128 = ops.set_option("gemm_small_wgrad_launches", 0) - n0
+    finally:
+        ops.set_option("gemm_small", prev)
+    assert took128 == 0 if not small else took128 in (0, 1)
     for (dy, x, gw, gb), (gw1, gb1) in zip(probs, single):
         assert torch.equal(gw, gw1)
-        if x.shape[1] <= 256:                  # one tile along b: a single workgroup per a-range adds to each entry (no atomic order)
+        if x.shape[1] <= 256 and not took128:  # one tile along b: a single workgroup per a-range adds to each entry (no atomic order)
             assert torch.equal(gb, gb1)
         else:
             assert rel(gb, gb1) < 1e-6

@@ -87,7 +87,8 @@ def main():
     print("sum over the blocks of one step (us)".ljust(46) + "".join(f"{tot[n]:8.0f}" for n, _, _ in variants))
 
     # weight-gradient pairs: the split rule
-    print("\nweight-gradient pairs (us): split chosen by ops._splitk_for, and every split 1 .. 8 forced")
+    print("\nweight-gradient pairs (us): the library's choice; the 256-tile pair kernel with the split ops._splitk_for chooses, unsplit with "
+          "each of its three epilogues, and with every split 1 .. 8 forced")
     for B in vols:
         for name, M, D in (("enc", B * 1281, 1024), ("dec", B * 5121, 512)):
             y1 = rnd(M, D); act = rnd(M, 4 * D); dpre = rnd(M, 4 * D); o = rnd(M, D); dqkv = rnd(M, 3 * D)
@@ -97,7 +98,9 @@ def main():
                 tiles = sum(((dy.shape[1] + 255) // 256) * ((xx.shape[1] + 255) // 256) for dy, xx, _, _ in (first, second))
                 chosen = ops._splitk_for(tiles, (M + 63) // 64, 256)
                 orig = ops._splitk_for
-                t_auto = timeit(lambda: ops.linear_wgrad_accum_pair(first, second))
+                t_auto = timeit(lambda: ops.linear_wgrad_accum_pair(first, second))          # the library's choice (may be the 128-tile pair kernel)
+                prev_small = ops.set_option("gemm_small", 0)                                    # everything below: the 256-tile pair kernel
+                t_rule256 = timeit(lambda: ops.linear_wgrad_accum_pair(first, second))
                 ops._splitk_for = lambda a, b_, c: 1
                 t_s1 = []
                 prev_opt = ops.set_option("wgrad_s1_atomic", 0)
@@ -110,7 +113,8 @@ def main():
                     ops._splitk_for = lambda a, b_, c, S=S: S
                     row.append(timeit(lambda: ops.linear_wgrad_accum_pair(first, second)))
                 ops._splitk_for = orig
-                print(f"B={B} {name} {pname:9s} tiles {tiles:4d} ktiles {(M + 63) // 64:5d}  rule S={chosen}: {t_auto:7.1f}  S=1 rmw/atomic/batched: " + "/".join(f"{t:.1f}" for t in t_s1) + "   forced: " +
+                ops.set_option("gemm_small", prev_small)
+                print(f"B={B} {name} {pname:9s} tiles {tiles:4d} ktiles {(M + 63) // 64:5d}  library: {t_auto:7.1f}  256-tile pair, rule S={chosen}: {t_rule256:7.1f}  S=1 rmw/atomic/batched: " + "/".join(f"{t:.1f}" for t in t_s1) + "   forced: " +
                       " ".join(f"{t:7.1f}" for t in row), flush=True)
 
 
