@@ -6,7 +6,12 @@ zero_grad on step boundaries, min/max group LR logging, scalar loss all-reduce.
 Not reproduced: the per-iteration ``torch.cuda.synchronize()`` and logits printing (pipeline stalls with no numerical effect),
 the 2-D/3-D ``variable_joint`` and SLIViT reshapes (models outside SURVEY §8), and the CSV / confusion-matrix reporting of
 the reference's ``evaluate`` -- this one returns loss, top-1 accuracy and the gathered logits / targets for the caller's
-metric code."""
+metric code.
+
+Provenance, stated once: this file is a RESTATEMENT of the reference's host loop, written to be call-compatible with it -- same
+function signatures, same order of operations per iteration, same ``MetricLogger`` keys -- because it is the caller SURVEY section 8
+(R14 / N1, N3) requires and the reference's drivers import it by name.  It holds no kernel logic; everything it calls (models, scaler,
+optimizer, schedules) is this package's own."""
 from __future__ import annotations
 
 import math

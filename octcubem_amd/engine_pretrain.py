@@ -7,7 +7,12 @@ epoch schedules of the joint recipe.
 per-iteration LR schedule -> H2D -> forward -> non-finite guard -> loss_scaler(backward / [all-reduce] / clip / step)
 -> zero_grad -> logging.  The dead ``get_mask`` work of the 3-D engine (its result is dropped by forward) and the
 per-iteration full-device synchronise are not reproduced; a single ``loss.item()`` per iteration remains (it is the
-reference's non-finite guard)."""
+reference's non-finite guard).
+
+Provenance, stated once: this file is a RESTATEMENT of the reference's host loop, written to be call-compatible with it -- same
+function signatures, same order of operations per iteration, same ``MetricLogger`` keys -- because it is the caller SURVEY section 8
+(R14 / N1, N3) requires and the reference's drivers import it by name.  It holds no kernel logic; everything it calls (models, scaler,
+optimizer, schedules) is this package's own."""
 from __future__ import annotations
 
 import math
