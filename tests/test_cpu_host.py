@@ -403,3 +403,26 @@ def test_small_launch_plan():
         assert plan(1024, 1281, 4096)[0] == 0                                              # switched off: never
     finally:
         lib.octmae_set_option(b"gemm_small", prev)
+
+
+def test_weight_gradient_split_rule():
+    """ops._splitk_for (host arithmetic): as many k slices as keep tiles x slices within one round of 256 workgroups with >= 8 k-tiles
+    each -- unless the fp32-atomic epilogues of the slices (0.22 us per tile and slice) cost more than the main-loop time they save
+    (1.4 us per k-tile): one or two volumes per step stay unsplit where round 5 split two ways; from 8 volumes on nothing changes
+    (the headline's choices are those of rounds 2-5)."""
+    from octcubem_amd import ops
+    enc_fc, enc_qkv, dec_fc, dec_qkv = 128, 64, 32, 16          # 256 x 256 output tiles of the four weight-gradient pairs of ViT-L
+    kt = lambda rows: (rows + 63) // 64
+    for vols in (8, 16, 32, 64, 128):                           # unchanged from the old rule
+        assert ops._splitk_for(enc_fc, kt(vols * 1281), 256) == 2
+        assert ops._splitk_for(enc_qkv, kt(vols * 1281), 256) == 4
+        assert ops._splitk_for(dec_fc, kt(vols * 5121), 256) == 8
+        assert ops._splitk_for(dec_qkv, kt(vols * 5121), 256) in (15, 16)
+    assert ops._splitk_for(enc_fc, kt(1281), 256) == 1 and ops._splitk_for(enc_qkv, kt(1281), 256) == 1       # one volume: no atomics
+    assert ops._splitk_for(enc_fc, kt(2 * 1281), 256) == 1 and ops._splitk_for(enc_qkv, kt(2 * 1281), 256) == 2
+    assert 3 <= ops._splitk_for(dec_fc, kt(5121), 256) <= 5 and 5 <= ops._splitk_for(dec_qkv, kt(5121), 256) <= 7
+    for tiles in (1, 7, 16, 64, 128, 300):                      # always a legal split
+        for ktiles in (1, 5, 8, 21, 81, 2562):
+            s_ = ops._splitk_for(tiles, ktiles, 256)
+            assert 1 <= s_ <= max(1, 256 // tiles) and (s_ == 1 or ktiles // s_ >= 8)
+            assert ops._splitk_for(tiles, ktiles, 1024) >= 1   # the 128-tile register-staged kernel's target: the old rule
