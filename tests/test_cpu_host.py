@@ -426,3 +426,13 @@ def test_weight_gradient_split_rule():
             s_ = ops._splitk_for(tiles, ktiles, 256)
             assert 1 <= s_ <= max(1, 256 // tiles) and (s_ == 1 or ktiles // s_ >= 8)
             assert ops._splitk_for(tiles, ktiles, 1024) >= 1   # the 128-tile register-staged kernel's target: the old rule
+
+
+def test_bench_parity_compliant_child_failure_is_recorded_not_raised():
+    """bench.py's `parity_compliant` record comes from a child process on the half-operand build; whatever goes wrong there (here: no GPU
+    in this container, so the child exits with an error) must end up IN the record -- the headline run goes on."""
+    import argparse
+    import bench
+    rec = bench.run_parity_compliant_child(argparse.Namespace(global_batch=256, micro_batch=0), steps=1, warmup=0)
+    assert rec["dtype"] == "f16" and rec["lib"] == "liboctmae_f16.so" and rec["value"] is None
+    assert "error" in rec and rec["error"]
